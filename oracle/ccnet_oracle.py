@@ -1,0 +1,401 @@
+"""CPU oracle for the CCNet inference hot path -- TEST INFRASTRUCTURE ONLY.
+
+A functional restatement (plain torch fp32 ops on a state_dict) of the reference's
+`Net.forward` -> `decode_outputs` -> `post_process` path.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this; the product package `ccnet_amd` never does.
+
+Pinned against the real reference (imported in the build container from /root/reference by
+oracle/make_golden.py) through the fixtures in tests/golden/.  The NMS arithmetic lives in
+torchvision (pinned 0.9.0, requirements.txt:10, not vendored, not installed): that part is
+"parity unpinned" by the reference and restated here from the published kernel (see nms_reference).
+
+Reference citations (all relative to the reference repo root):
+  network/model_block.py:37-58   BaseConv          -> conv_bn_act
+  network/model_block.py:61-83   SPPFBottleneck    -> sppf
+  network/model_block.py:86-116  CSPLayer          -> csp
+  network/model_block.py:119-149 AMFFCSPLayer      -> csp(amff=True)
+  network/model_block.py:152-175 SpaceToDepth      -> s2d_conv
+  network/model_block.py:178-190 FocusReplaceConv  -> conv_bn_act(k=6,s=2,p=2)
+  network/model_block.py:193-245 Bottleneck / AMFFBottleneck
+  network/model_block.py:248-298 MobileViT (+ torch.nn.Transformer semantics) -> mobilevit
+  network/model_block.py:308-412 ASFFConv / ASFF   -> asff
+  network/attention_block.py:6-70  CBAM            -> cbam
+  network/attention_block.py:74-102 ECA            -> eca
+  network/net.py:194-275, net_deploy.py:189-270, net_amff.py:203-298, net_small_target.py:201-300
+  utils/bbox.py:13-79  decode_outputs ; utils/bbox.py:82-159 post_process
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_BN_EPS = 1e-5
+_LN_EPS = 1e-5
+
+
+# ----------------------------------------------------------------------------- activations
+def activation(name):
+    # model_block.py:14-34
+    if name == "silu":
+        return F.silu
+    if name == "relu":
+        return F.relu
+    if name == "relu6":
+        return F.relu6
+    if name == "lrelu":
+        return lambda t: F.leaky_relu(t, 0.1)
+    raise AttributeError("Unsupported activation function type: {}".format(name))
+
+
+# ----------------------------------------------------------------------------- blocks
+def _bn(sd, p, x):
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                        False, 0.0, _BN_EPS)
+
+
+def conv_bn_act(sd, p, x, stride, act, pad=None):
+    """BaseConv / FocusReplaceConv / ASFFConv: conv (no bias) + eval BN + act."""
+    w = sd[p + ".conv.weight"]
+    k = w.shape[-1]
+    if pad is None:
+        pad = (k - 1) // 2
+    return act(_bn(sd, p + ".bn", F.conv2d(x, w, None, stride, pad)))
+
+
+def s2d_conv(sd, p, x, act):
+    """SpaceToDepth: TL, TR, BL, BR channel concat (model_block.py:169-173) then BaseConv k3 s1."""
+    x = torch.cat((x[..., ::2, ::2], x[..., ::2, 1::2], x[..., 1::2, ::2], x[..., 1::2, 1::2]), 1)
+    return conv_bn_act(sd, p + ".conv", x, 1, act)
+
+
+def bottleneck(sd, p, x, shortcut, act):
+    y = conv_bn_act(sd, p + ".conv2", conv_bn_act(sd, p + ".conv1", x, 1, act), 1, act)
+    cin = sd[p + ".conv1.conv.weight"].shape[1]
+    cout = sd[p + ".conv2.conv.weight"].shape[0]
+    return y + x if (shortcut and cin == cout) else y
+
+
+def amff_bottleneck(sd, p, x, shortcut, act):
+    # conv1x1 -> BN (no act) -> conv3x3 (no BN) -> act -> (+x)   model_block.py:237-245
+    y = F.conv2d(x, sd[p + ".conv1.weight"])
+    y = _bn(sd, p + ".bn", y)
+    y = act(F.conv2d(y, sd[p + ".conv2.weight"], None, 1, 1))
+    cin = sd[p + ".conv1.weight"].shape[1]
+    cout = sd[p + ".conv2.weight"].shape[0]
+    return y + x if (shortcut and cin == cout) else y
+
+
+def csp(sd, p, x, n, shortcut, act, amff=False):
+    x1 = conv_bn_act(sd, p + ".conv1", x, 1, act)
+    x2 = conv_bn_act(sd, p + ".conv2", x, 1, act)
+    for i in range(n):
+        blk = amff_bottleneck if amff else bottleneck
+        x1 = blk(sd, "%s.m.%d" % (p, i), x1, shortcut, act)
+    return conv_bn_act(sd, p + ".conv3", torch.cat((x1, x2), 1), 1, act)
+
+
+def sppf(sd, p, x, act):
+    x = conv_bn_act(sd, p + ".conv1", x, 1, act)
+    y1 = F.max_pool2d(x, 5, 1, 2)
+    y2 = F.max_pool2d(y1, 5, 1, 2)
+    y3 = F.max_pool2d(y2, 5, 1, 2)
+    return conv_bn_act(sd, p + ".conv2", torch.cat((x, y1, y2, y3), 1), 1, act)
+
+
+def cbam(sd, p, x):
+    ca = p + ".channel_attention"
+    w1, w2 = sd[ca + ".fc1.weight"], sd[ca + ".fc2.weight"]
+
+    def mlp(v):
+        return F.conv2d(F.relu(F.conv2d(v, w1)), w2)
+
+    gate = torch.sigmoid(mlp(F.adaptive_avg_pool2d(x, 1)) + mlp(F.adaptive_max_pool2d(x, 1)))
+    x = x * gate
+    s = torch.cat([x.mean(1, keepdim=True), x.max(1, keepdim=True)[0]], 1)
+    wk = sd[p + ".spatial_attention.conv1.weight"]
+    return x * torch.sigmoid(F.conv2d(s, wk, None, 1, wk.shape[-1] // 2))
+
+
+def eca(sd, p, x):
+    y = F.adaptive_avg_pool2d(x, 1)  # (B,C,1,1)
+    w = sd[p + ".conv.weight"]
+    y = F.conv1d(y.squeeze(-1).transpose(-1, -2), w, None, 1, (w.shape[-1] - 1) // 2).transpose(-1, -2).unsqueeze(-1)
+    return x * torch.sigmoid(y)
+
+
+def _layer_norm(sd, p, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], _LN_EPS)
+
+
+def _mha(sd, p, q_in, kv_in, nhead):
+    """torch.nn.MultiheadAttention, batch_first=False: inputs (S, N, E); S is the attended axis."""
+    E = q_in.shape[-1]
+    W, b = sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"]
+    q = F.linear(q_in, W[:E], b[:E])
+    k = F.linear(kv_in, W[E:2 * E], b[E:2 * E])
+    v = F.linear(kv_in, W[2 * E:], b[2 * E:])
+    Sq, N, _ = q.shape
+    Sk = k.shape[0]
+    hd = E // nhead
+    q = q.reshape(Sq, N * nhead, hd).transpose(0, 1)
+    k = k.reshape(Sk, N * nhead, hd).transpose(0, 1)
+    v = v.reshape(Sk, N * nhead, hd).transpose(0, 1)
+    att = torch.softmax(torch.bmm(q, k.transpose(1, 2)) / math.sqrt(hd), dim=-1)
+    o = torch.bmm(att, v).transpose(0, 1).reshape(Sq, N, E)
+    return F.linear(o, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
+
+
+def _ffn(sd, p, x):
+    return F.linear(F.relu(F.linear(x, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+                    sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+
+
+def transformer(sd, p, src, nhead, n_enc, n_dec):
+    """nn.Transformer(src, tgt=src) in eval mode: post-norm, ReLU, no masks (model_block.py:270-271,290)."""
+    x = src
+    for i in range(n_enc):
+        q = "%s.encoder.layers.%d" % (p, i)
+        x = _layer_norm(sd, q + ".norm1", x + _mha(sd, q + ".self_attn", x, x, nhead))
+        x = _layer_norm(sd, q + ".norm2", x + _ffn(sd, q, x))
+    mem = _layer_norm(sd, p + ".encoder.norm", x)
+    y = src
+    for i in range(n_dec):
+        q = "%s.decoder.layers.%d" % (p, i)
+        y = _layer_norm(sd, q + ".norm1", y + _mha(sd, q + ".self_attn", y, y, nhead))
+        y = _layer_norm(sd, q + ".norm2", y + _mha(sd, q + ".multihead_attn", y, mem, nhead))
+        y = _layer_norm(sd, q + ".norm3", y + _ffn(sd, q, y))
+    return _layer_norm(sd, p + ".decoder.norm", y)
+
+
+def mobilevit(sd, p, x, nhead=2, n_enc=6, n_dec=6):
+    B, C, H, W = x.shape
+    y = F.conv2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], 1, 1, 1, C)  # depthwise
+    y = F.conv2d(y, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"])
+    d = y.shape[1]
+    # (B, HW, d) fed to a batch_first=False Transformer: axis 0 (the image batch) is the sequence
+    t = y.permute(0, 2, 3, 1).reshape(B, H * W, d)
+    t = transformer(sd, p + ".transformer", t, nhead, n_enc, n_dec)
+    y = t.reshape(B, H, W, d).permute(0, 3, 1, 2)
+    y = F.conv2d(y, sd[p + ".conv3.weight"], sd[p + ".conv3.bias"])
+    return F.conv2d(torch.cat([x, y], 1), sd[p + ".conv4.weight"], sd[p + ".conv4.bias"], 1, 1)
+
+
+def asff(sd, p, level, pan):
+    """pan = (pan_out2, pan_out1, pan_out0); level 0 works at pan_out0's resolution (model_block.py:364-412)."""
+    silu = F.silu
+    l0, l1, l2 = pan[2], pan[1], pan[0]
+    if level == 0:
+        r0 = l0
+        r1 = conv_bn_act(sd, p + ".stride_level_1", l1, 2, silu, 1)
+        r2 = conv_bn_act(sd, p + ".stride_level_2", F.max_pool2d(l2, 3, 2, 1), 2, silu, 1)
+    elif level == 1:
+        r0 = F.interpolate(conv_bn_act(sd, p + ".compress_level_0", l0, 1, silu, 0), scale_factor=2, mode="nearest")
+        r1 = l1
+        r2 = conv_bn_act(sd, p + ".stride_level_2", l2, 2, silu, 1)
+    else:
+        r0 = F.interpolate(conv_bn_act(sd, p + ".compress_level_0", l0, 1, silu, 0), scale_factor=4, mode="nearest")
+        r1 = F.interpolate(conv_bn_act(sd, p + ".compress_level_1", l1, 1, silu, 0), scale_factor=2, mode="nearest")
+        r2 = l2
+    wv = torch.cat((conv_bn_act(sd, p + ".weight_level_0", r0, 1, silu, 0),
+                    conv_bn_act(sd, p + ".weight_level_1", r1, 1, silu, 0),
+                    conv_bn_act(sd, p + ".weight_level_2", r2, 1, silu, 0)), 1)
+    wgt = torch.softmax(conv_bn_act(sd, p + ".weight_levels", wv, 1, silu, 0), dim=1)
+    fused = r0 * wgt[:, 0:1] + r1 * wgt[:, 1:2] + r2 * wgt[:, 2:3]
+    return conv_bn_act(sd, p + ".expand", fused, 1, silu, 1)
+
+
+def head(sd, feats, act):
+    outs = []
+    for k, x in enumerate(feats):
+        x = conv_bn_act(sd, "stems.%d" % k, x, 1, act)
+        c = conv_bn_act(sd, "cls_convs.%d.1" % k, conv_bn_act(sd, "cls_convs.%d.0" % k, x, 1, act), 1, act)
+        r = conv_bn_act(sd, "reg_convs.%d.1" % k, conv_bn_act(sd, "reg_convs.%d.0" % k, x, 1, act), 1, act)
+        cls = F.conv2d(c, sd["cls_preds.%d.weight" % k], sd["cls_preds.%d.bias" % k])
+        reg = F.conv2d(r, sd["reg_preds.%d.weight" % k], sd["reg_preds.%d.bias" % k])
+        obj = F.conv2d(r, sd["obj_preds.%d.weight" % k], sd["obj_preds.%d.bias" % k])
+        outs.append(torch.cat([reg, obj, cls], 1))
+    return outs
+
+
+def _up(x):
+    return F.interpolate(x, scale_factor=2, mode="nearest")
+
+
+# ----------------------------------------------------------------------------- the four nets
+def forward(kind, sd, x, depth=1.0, width=1.0, act="silu", taps=None):
+    """kind in {"net","net_deploy","net_amff","net_small_target"}.  Returns the list of raw head maps
+    (B, 5+nc, H_k, W_k).  `taps`, if a dict, receives named intermediate tensors."""
+    a = activation(act)
+    bd = max(round(depth * 3), 1)
+    nn_ = round(3 * depth)
+    silu = F.silu
+    amff = kind == "net_amff"
+
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t
+        return t
+
+    with torch.no_grad():
+        if kind == "net":
+            l0 = tap("stem", s2d_conv(sd, "stem", x, a))
+            l1 = tap("dark2", csp(sd, "dark2.1", s2d_conv(sd, "dark2.0", l0, a), bd, True, a))
+            l2 = tap("dark3", csp(sd, "dark3.1", s2d_conv(sd, "dark3.0", l1, a), bd, True, a))
+            l3 = tap("dark4", csp(sd, "dark4.1", s2d_conv(sd, "dark4.0", l2, a), bd * 3, True, a))
+            t = s2d_conv(sd, "dark5.0", l3, a)
+            t = tap("sppf", sppf(sd, "dark5.1", t, a))
+            t = tap("mobilevit", mobilevit(sd, "dark5.2", t))
+            l4 = tap("dark5", csp(sd, "dark5.3", t, bd, False, a))
+        else:
+            # FocusReplaceConv never receives `act`: always SiLU (net_deploy.py:41, model_block.py:179)
+            l0 = tap("stem", silu(_bn(sd, "stem.bn", F.conv2d(x, sd["stem.conv.weight"], None, 2, 2))))
+            n3 = bd * 3
+            l1 = tap("dark2", csp(sd, "dark2.1", conv_bn_act(sd, "dark2.0", l0, 2, a), bd, True, a, amff))
+            l2 = tap("dark3", csp(sd, "dark3.1", conv_bn_act(sd, "dark3.0", l1, 2, a), n3, True, a, amff))
+            l3 = tap("dark4", csp(sd, "dark4.1", conv_bn_act(sd, "dark4.0", l2, 2, a), n3, True, a, amff))
+            t = conv_bn_act(sd, "dark5.0", l3, 2, a)
+            t = tap("sppf", sppf(sd, "dark5.1", t, a))
+            l4 = tap("dark5", csp(sd, "dark5.2", t, bd, False, a, amff))
+
+        def down(p, t):
+            return s2d_conv(sd, p, t, a) if kind == "net" else conv_bn_act(sd, p, t, 2, a)
+
+        if amff:
+            g2, g3, g4 = eca(sd, "eca_3", l2), eca(sd, "eca_2", l3), eca(sd, "eca_1", l4)
+        else:
+            g2, g3, g4 = cbam(sd, "layer2_cbam", l2), cbam(sd, "layer3_cbam", l3), cbam(sd, "layer4_cbam", l4)
+        tap("gate2", g2), tap("gate3", g3), tap("gate4", g4)
+
+        fpn0 = conv_bn_act(sd, "lateral_conv0", g4, 1, a)
+        f0 = csp(sd, "C3_p4", torch.cat([_up(fpn0), g3], 1), nn_, False, a, amff)
+        if amff:
+            f0 = eca(sd, "eca_fp1", f0)
+        fpn1 = conv_bn_act(sd, "reduce_conv1", f0, 1, a)
+        p2 = csp(sd, "C3_p3", torch.cat([_up(fpn1), g2], 1), nn_, False, a, amff)
+        if amff:
+            p2 = eca(sd, "eca_pa1", p2)
+
+        if kind == "net_small_target":
+            g1 = tap("gate1", cbam(sd, "layer1_cbam", l1))
+            fpn2 = conv_bn_act(sd, "reduce_conv2", p2, 1, a)
+            p3 = csp(sd, "C3_p2", torch.cat([_up(fpn2), g1], 1), nn_, False, a)
+            p2 = csp(sd, "C3_n2", torch.cat([conv_bn_act(sd, "bu_conv3", p3, 2, a), fpn2], 1), nn_, False, a)
+
+        p1 = csp(sd, "C3_n3", torch.cat([down("bu_conv2", p2), fpn1], 1), nn_, False, a, amff)
+        if amff:
+            p1 = eca(sd, "eca_pa2", p1)
+        p0 = csp(sd, "C3_n4", torch.cat([down("bu_conv1", p1), fpn0], 1), nn_, False, a, amff)
+        if amff:
+            p0 = eca(sd, "eca_pa3", p0)
+            pan = (p2, p1, p0)
+            p0, p1, p2 = asff(sd, "asff_1", 0, pan), asff(sd, "asff_2", 1, pan), asff(sd, "asff_3", 2, pan)
+        tap("pan_out2", p2), tap("pan_out1", p1), tap("pan_out0", p0)
+        feats = (p3, p2, p1, p0) if kind == "net_small_target" else (p2, p1, p0)
+        return head(sd, feats, a)
+
+
+# ----------------------------------------------------------------------------- decode
+def decode_outputs(outputs, input_shape):
+    """utils/bbox.py:13-79.  Returns a fresh contiguous (B, A, 5+nc) fp32 tensor; the arithmetic order
+    ((raw+grid)*stride, then /dim; stride = input_shape[0]/h for both axes) follows the reference."""
+    hw = [tuple(o.shape[-2:]) for o in outputs]
+    # keep the reference's memory layout (a permuted view of the (B, C, A) cat) while computing: ATen's
+    # sigmoid/exp round differently on strided and contiguous operands, and the fixtures pin the former
+    out = torch.cat([o.detach().cpu().float().flatten(2) for o in outputs], 2).permute(0, 2, 1)
+    out[:, :, 4:] = torch.sigmoid(out[:, :, 4:])
+    grids, strides = [], []
+    for h, w in hw:
+        gy, gx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+        grids.append(torch.stack((gx, gy), 2).reshape(1, -1, 2).float())
+        strides.append(torch.full((1, h * w, 1), input_shape[0] / h, dtype=torch.float32))
+    grids, strides = torch.cat(grids, 1), torch.cat(strides, 1)
+    out[..., :2] = (out[..., :2] + grids) * strides
+    out[..., 2:4] = torch.exp(out[..., 2:4]) * strides
+    out[..., [0, 2]] = out[..., [0, 2]] / input_shape[1]
+    out[..., [1, 3]] = out[..., [1, 3]] / input_shape[0]
+    return out.contiguous()
+
+
+# ----------------------------------------------------------------------------- NMS
+def nms_reference(boxes, scores, iou_threshold):
+    """Greedy NMS as in torchvision 0.9.0 ops/cpu/nms_kernel.cpp (third party, not vendored; parity unpinned):
+    fp32 areas (x2-x1)*(y2-y1); order = descending scores, *stable* (ties keep the lower index first --
+    the build's pin, torch 1.8 sort made no promise); for each kept i, every later j with
+    inter/(area_i+area_j-inter) > thr (float ovr promoted to double thr) is suppressed.  NaN never suppresses.
+    boxes (n,4) float32 numpy, scores (n,) float32.  Returns kept indices (int64) in score order."""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    n = boxes.shape[0]
+    if n == 0:
+        return np.zeros((0,), dtype=np.int64)
+    x1, y1, x2, y2 = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
+    areas = (x2 - x1) * (y2 - y1)
+    order = np.argsort(-scores.astype(np.float64), kind="stable")
+    # float ovr > double thr  <=>  float ovr > largest float <= thr
+    thr = float(iou_threshold)
+    suppressed = np.zeros(n, dtype=bool)
+    keep = []
+    zero = np.float32(0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for pos in range(n):
+            i = order[pos]
+            if suppressed[i]:
+                continue
+            keep.append(i)
+            rest = order[pos + 1:]
+            if rest.size == 0:
+                break
+            w = np.maximum(zero, np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]))
+            h = np.maximum(zero, np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]))
+            inter = w * h
+            ovr = inter / ((areas[i] + areas[rest]) - inter)
+            suppressed[rest[ovr.astype(np.float64) > thr]] = True
+    return np.asarray(keep, dtype=np.int64)
+
+
+def batched_nms_reference(boxes, scores, idxs, iou_threshold):
+    """torchvision 0.9.0 ops/boxes.py batched_nms: the coordinate trick, no per-class loop.
+    offsets = idxs.to(boxes) * (boxes.max() + 1); nms(boxes + offsets[:, None])."""
+    boxes = np.asarray(boxes, dtype=np.float32)
+    if boxes.shape[0] == 0:
+        return np.zeros((0,), dtype=np.int64)
+    max_c = boxes.max()
+    offsets = np.asarray(idxs, dtype=np.float32) * (max_c + np.float32(1))
+    return nms_reference(boxes + offsets[:, None], scores, iou_threshold)
+
+
+def post_process(prediction, num_classes, input_shape, image_info, conf_thres=0.5, nms_thres=0.4, nms_fn=None):
+    """utils/bbox.py:82-159 on a (B, A, 5+nc) decoded tensor (not modified).  Returns list of (n,7) float32
+    arrays [top, left, bottom, right, obj_conf, class_conf, class_id] in original-image pixels."""
+    if nms_fn is None:
+        nms_fn = batched_nms_reference
+    pred = prediction.detach().cpu().float().clone()
+    corner = pred.clone()
+    corner[:, :, 0] = pred[:, :, 0] - pred[:, :, 2] / 2
+    corner[:, :, 1] = pred[:, :, 1] - pred[:, :, 3] / 2
+    corner[:, :, 2] = pred[:, :, 0] + pred[:, :, 2] / 2
+    corner[:, :, 3] = pred[:, :, 1] + pred[:, :, 3] / 2
+    pred[:, :, :4] = corner[:, :, :4]
+    results = []
+    for i in range(pred.shape[0]):
+        p = pred[i]
+        if p.shape[0] == 0:
+            results.append(None)
+            continue
+        cconf, cpred = torch.max(p[:, 5:5 + num_classes], 1, keepdim=True)
+        mask = (p[:, 4] * cconf[:, 0]) >= conf_thres
+        det = torch.cat((p[:, :5], cconf, cpred.float()), 1)[mask]
+        keep = nms_fn(det[:, :4].numpy(), (det[:, 4] * det[:, 5]).numpy(), det[:, 6].numpy(), nms_thres)
+        out = det[torch.as_tensor(keep, dtype=torch.long)].numpy().copy()
+        # numpy tail of the reference (bbox.py:145-158): yx order, scale by [ih, iw, ih, iw] in float64
+        xy = (out[:, 0:2] + out[:, 2:4]) / 2
+        wh = out[:, 2:4] - out[:, 0:2]
+        yx, hw_ = xy[..., ::-1], wh[..., ::-1]
+        image_shape = np.array([image_info[i][2], image_info[i][1]])
+        mins, maxes = yx - (hw_ / 2.), yx + (hw_ / 2.)
+        re_boxes = np.concatenate([mins[..., 0:1], mins[..., 1:2], maxes[..., 0:1], maxes[..., 1:2]], axis=-1)
+        re_boxes *= np.concatenate([image_shape, image_shape], axis=-1)
+        out[:, :4] = re_boxes
+        results.append(out)
+    return results
