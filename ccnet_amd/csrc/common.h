@@ -1,0 +1,114 @@
+// Shared host/device helpers for libccnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <functional>
+#include "../../include/ccnet_hip.h"
+
+// ---- error plumbing -------------------------------------------------------------------------------------
+int ccnet_set_error(int code, const char* fmt, ...);
+
+#define CC_REQUIRE(cond, ...)                                  \
+    do {                                                       \
+        if (!(cond)) return ccnet_set_error(CCNET_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+#define CC_HIP(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return ccnet_set_error(CCNET_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define CC_LAUNCH_CHECK()                                                                               \
+    do {                                                                                                \
+        hipError_t e_ = hipGetLastError();                                                              \
+        if (e_ != hipSuccess) return ccnet_set_error(CCNET_EHIP, "kernel launch failed: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+// A recorded or immediate launch.  x_override replaces the stem image pointer when not null.
+using ccnet_launch_fn = std::function<int(hipStream_t, const float* x_override)>;
+// Runs `fn` now on `stream`, or appends it to the calling thread's open plan.
+int ccnet_submit(ccnet_launch_fn fn, ccnet_stream stream);
+
+static inline bool cc_dtype_ok(int d) { return d == CCNET_F32 || d == CCNET_BF16; }
+static inline int cc_esize(int d) { return d == CCNET_BF16 ? 2 : 4; }
+// read operands: 16-byte vector access on channel groups
+static inline bool cc_slice_vec_ok(const ccnet_slice& s, int dtype) {
+    int g = 16 / cc_esize(dtype);
+    return s.ptr && s.C > 0 && s.ldc >= s.coff + s.C && s.coff >= 0 && (s.ldc % g) == 0 && (s.coff % g) == 0 &&
+           (s.C % g) == 0 && ((uintptr_t)s.ptr % 16) == 0 && s.shift >= 0 && s.shift <= 3;
+}
+
+// ---- device helpers -------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float x) {
+    __bf16 h = (__bf16)x;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return (uint32_t)__builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+// 8 consecutive channels <-> fp32
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = bf16_bits_to_f32(v.x & 0xFFFFu); f[1] = bf16_bits_to_f32(v.x >> 16);
+    f[2] = bf16_bits_to_f32(v.y & 0xFFFFu); f[3] = bf16_bits_to_f32(v.y >> 16);
+    f[4] = bf16_bits_to_f32(v.z & 0xFFFFu); f[5] = bf16_bits_to_f32(v.z >> 16);
+    f[6] = bf16_bits_to_f32(v.w & 0xFFFFu); f[7] = bf16_bits_to_f32(v.w >> 16);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+    return v;
+}
+
+// Load / store a group of 8 consecutive channels as fp32, for either storage type.
+template <typename T> struct Chan8;
+template <> struct Chan8<__bf16> {
+    static __device__ __forceinline__ void load(const void* p, float* f) { unpack8(*(const uint4*)p, f); }
+    static __device__ __forceinline__ void store(void* p, const float* f) { *(uint4*)p = pack8(f); }
+};
+template <> struct Chan8<float> {
+    static __device__ __forceinline__ void load(const void* p, float* f) {
+        float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(void* p, const float* f) {
+        ((float4*)p)[0] = make_float4(f[0], f[1], f[2], f[3]);
+        ((float4*)p)[1] = make_float4(f[4], f[5], f[6], f[7]);
+    }
+};
+template <typename T> __device__ __forceinline__ float load1(const T* p);
+template <> __device__ __forceinline__ float load1<__bf16>(const __bf16* p) { return (float)*p; }
+template <> __device__ __forceinline__ float load1<float>(const float* p) { return *p; }
+template <typename T> __device__ __forceinline__ void store1(T* p, float v);
+template <> __device__ __forceinline__ void store1<__bf16>(__bf16* p, float v) { *p = (__bf16)v; }
+template <> __device__ __forceinline__ void store1<float>(float* p, float v) { *p = v; }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float apply_act(float x, int act) {
+    switch (act) {
+        case CCNET_ACT_SILU: return x * sigmoidf_(x);
+        case CCNET_ACT_RELU: return fmaxf(x, 0.0f);
+        case CCNET_ACT_RELU6: return fminf(fmaxf(x, 0.0f), 6.0f);
+        case CCNET_ACT_LRELU: return x > 0.0f ? x : 0.1f * x;
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+#endif  // __HIPCC__

@@ -1,0 +1,341 @@
+// decode_outputs + post_process on the GPU (compile this file with -ffp-contract=off: the box arithmetic must
+// round exactly like the reference's separate fp32 tensor ops, so no FMA contraction anywhere in here).
+//
+//   decode   : sigmoid / exp / grid, one thread per anchor                       (utils/bbox.py:36-76)
+//   filter   : xyxy, class max, conf mask, stable compaction, one block per image (utils/bbox.py:98-130)
+//   nms      : coordinate-trick batched NMS                                       (utils/bbox.py:133-138 -> torchvision)
+//              prepare (max coordinate, offset boxes, scores) -> rank sort (stable, descending)
+//              -> 64x64 IoU bitmask tiles (one wave per tile, one 64-bit word per lane)
+//              -> sequential sweep, 64 boxes at a time resolved in registers -> gather + rescale (utils/bbox.py:145-158)
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+constexpr int MAXLEV = 8;
+struct DecodeP {
+    const float* head[MAXLEV];
+    long long sb[MAXLEV], sc[MAXLEV], sp[MAXLEV];
+    int h[MAXLEV], w[MAXLEV], a0[MAXLEV + 1];
+    float stride[MAXLEV];
+    int nlev, B, A, nch;
+    float in_h, in_w;
+    float* out;
+};
+
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeP p) {
+    long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.B * p.A) return;
+    const int a = (int)(idx % p.A), b = (int)(idx / p.A);
+    int l = 0;
+    while (l + 1 < p.nlev && a >= p.a0[l + 1]) ++l;
+    const int r = a - p.a0[l];
+    const int gy = r / p.w[l], gx = r - gy * p.w[l];
+    const float* src = p.head[l] + (long long)b * p.sb[l] + (long long)r * p.sp[l];
+    float* dst = p.out + idx * p.nch;
+    const float s = p.stride[l];
+    const long long sc = p.sc[l];
+    // ((raw + grid) * stride) / dim, exp(raw) * stride / dim: same op order as bbox.py:70-76
+    dst[0] = ((src[0] + (float)gx) * s) / p.in_w;
+    dst[1] = ((src[sc] + (float)gy) * s) / p.in_h;
+    dst[2] = (expf(src[2 * sc]) * s) / p.in_w;
+    dst[3] = (expf(src[3 * sc]) * s) / p.in_h;
+    for (int c = 4; c < p.nch; ++c) dst[c] = 1.0f / (1.0f + expf(-src[c * sc]));
+}
+
+// ---- filter: one block (1024 threads) per image, anchors in order, stable compaction
+__global__ __launch_bounds__(1024) void filter_kernel(const float* pred, int A, int nc, float conf, float* cand, int* counts) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nch = 5 + nc;
+    const float* pb = pred + (size_t)b * A * nch;
+    float* cb = cand + (size_t)b * A * 7;
+    if (t == 0) base_s = 0;
+    __syncthreads();
+    for (int a0 = 0; a0 < A; a0 += 1024) {
+        const int a = a0 + t;
+        bool keep = false;
+        float x1 = 0, y1 = 0, x2 = 0, y2 = 0, obj = 0, cc = 0;
+        int cp = 0;
+        if (a < A) {
+            const float* r = pb + (size_t)a * nch;
+            const float cx = r[0], cy = r[1], w = r[2], h = r[3];
+            x1 = cx - w / 2; y1 = cy - h / 2; x2 = cx + w / 2; y2 = cy + h / 2;
+            obj = r[4];
+            cc = r[5];
+            for (int c = 1; c < nc; ++c) {
+                float v = r[5 + c];
+                if (v > cc) { cc = v; cp = c; }  // strict >: first maximal index on ties (torch.max)
+            }
+            keep = (obj * cc) >= conf;
+        }
+        const unsigned long long bal = __ballot(keep);
+        const int within = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base_s;
+        for (int q = 0; q < wave; ++q) off += wsum[q];
+        if (keep) {
+            float* d = cb + (size_t)(off + within) * 7;
+            d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2; d[4] = obj; d[5] = cc; d[6] = (float)cp;
+        }
+        __syncthreads();
+        if (t == 0) {
+            int tot = 0;
+            for (int q = 0; q < 16; ++q) tot += wsum[q];
+            base_s += tot;
+        }
+        __syncthreads();
+    }
+    if (t == 0) counts[b] = base_s;
+}
+
+// ---- NMS workspace (per image, nmax boxes; W = ceil(nmax/64) words)
+struct NmsWs {
+    size_t boxes, scores, order, mask, total;  // byte offsets
+    int W;
+};
+NmsWs nms_ws(int B, int nmax) {
+    NmsWs w;
+    w.W = (nmax + 63) / 64;
+    size_t np = (size_t)w.W * 64;
+    w.boxes = 0;                                         // float4 [B][np]  offset boxes, later sorted boxes
+    w.scores = w.boxes + (size_t)B * np * 16 * 2;        // two float4 planes: unsorted, sorted
+    w.order = w.scores + (size_t)B * np * 4;             // float [B][np]
+    w.mask = w.order + (size_t)B * np * 4;               // int [B][np]
+    w.mask = (w.mask + 255) & ~(size_t)255;
+    w.total = w.mask + (size_t)B * np * w.W * 8;         // u64 [B][np][W]
+    return w;
+}
+
+// offset boxes = boxes + cls * (max_coordinate + 1)  (torchvision batched_nms coordinate trick); scores = obj * cls_conf
+__global__ __launch_bounds__(256) void nms_prepare_kernel(const float* cand, const int* counts, int A, int np, float4* boxes, float* scores) {
+    __shared__ float red[4];
+    __shared__ float maxc_s;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int n = counts[b];
+    const float* cb = cand + (size_t)b * A * 7;
+    float m = -INFINITY;
+    for (int i = t; i < n; i += 256) {
+        const float* r = cb + (size_t)i * 7;
+        m = fmaxf(m, fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])));
+    }
+    m = wave_max(m);
+    if ((t & 63) == 0) red[t >> 6] = m;
+    __syncthreads();
+    if (t == 0) maxc_s = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    const float step = maxc_s + 1.0f;
+    for (int i = t; i < n; i += 256) {
+        const float* r = cb + (size_t)i * 7;
+        const float off = r[6] * step;
+        boxes[(size_t)b * np + i] = make_float4(r[0] + off, r[1] + off, r[2] + off, r[3] + off);
+        scores[(size_t)b * np + i] = r[4] * r[5];
+    }
+}
+
+// stable descending rank: rank(i) = #{j : s_j > s_i or (s_j == s_i and j < i)}
+__global__ __launch_bounds__(256) void nms_rank_kernel(const int* counts, int np, const float4* boxes, const float* scores, float4* sboxes,
+                                                       int* order) {
+    __shared__ float tile[256];
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int n = counts[b];
+    if ((int)(blockIdx.x * 256) >= n) return;
+    const int i = blockIdx.x * 256 + t;
+    const float* sb = scores + (size_t)b * np;
+    const float si = i < n ? sb[i] : 0.0f;
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        __syncthreads();
+        tile[t] = (j0 + t < n) ? sb[j0 + t] : -INFINITY;
+        __syncthreads();
+        const int jn = min(256, n - j0);
+        for (int j = 0; j < jn; ++j) {
+            const float sj = tile[j];
+            rank += (sj > si || (sj == si && (j0 + j) < i)) ? 1 : 0;
+        }
+    }
+    if (i < n) {
+        order[(size_t)b * np + rank] = i;
+        sboxes[(size_t)b * np + rank] = boxes[(size_t)b * np + i];
+    }
+}
+
+// one wave per 64x64 tile of the (sorted) pair matrix; lane = row, bit j = column
+__global__ __launch_bounds__(64) void nms_mask_kernel(const int* counts, int np, int W, const float4* sboxes, double thr, unsigned long long* mask) {
+    __shared__ float4 cols[64];
+    const int b = blockIdx.z, rb = blockIdx.y, cbk = blockIdx.x;
+    const int n = counts[b];
+    if (cbk < rb || rb * 64 >= n || cbk * 64 >= n) return;
+    const int lane = threadIdx.x;
+    const float4* sb = sboxes + (size_t)b * np;
+    const int ci = cbk * 64 + lane;
+    cols[lane] = ci < n ? sb[ci] : make_float4(0, 0, 0, 0);
+    __syncthreads();
+    const int i = rb * 64 + lane;
+    if (i >= n) return;
+    const float4 bi = sb[i];
+    const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+    unsigned long long bits = 0;
+    const int jn = min(64, n - cbk * 64);
+    for (int j = 0; j < jn; ++j) {
+        const int gj = cbk * 64 + j;
+        if (gj <= i) continue;
+        const float4 bj = cols[j];
+        const float aj = (bj.z - bj.x) * (bj.w - bj.y);
+        const float w = fmaxf(0.0f, fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x));
+        const float h = fmaxf(0.0f, fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y));
+        const float inter = w * h;
+        const float ovr = inter / ((ai + aj) - inter);
+        if ((double)ovr > thr) bits |= 1ull << j;  // NaN compares false: never suppresses
+    }
+    mask[((size_t)b * np + i) * W + cbk] = bits;
+}
+
+// one block per image: sweep the sorted boxes 64 at a time
+__global__ __launch_bounds__(256) void nms_sweep_kernel(const int* counts, int np, int W, const unsigned long long* mask, const int* order, int nmax,
+                                                        int* keep_idx, int* nkeep) {
+    extern __shared__ unsigned long long removed[];  // [W]
+    __shared__ unsigned long long kept_s;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int n = counts[b];
+    const int nw = (n + 63) / 64;
+    for (int w = t; w < nw; w += 256) removed[w] = 0ull;
+    __syncthreads();
+    const unsigned long long* mb = mask + (size_t)b * np * W;
+    const int* ob = order + (size_t)b * np;
+    int total = 0;  // meaningful in wave 0
+    for (int c = 0; c < nw; ++c) {
+        if (t < 64) {
+            const int i = c * 64 + t;
+            const unsigned long long diag = i < n ? mb[(size_t)i * W + c] : 0ull;
+            unsigned long long rem = removed[c];
+            unsigned long long kept = 0ull;
+            const int jn = min(64, n - c * 64);
+            for (int j = 0; j < jn; ++j) {
+                const unsigned long long dj = __shfl(diag, j, 64);
+                if (!((rem >> j) & 1ull)) {
+                    kept |= 1ull << j;
+                    rem |= dj;
+                }
+            }
+            if ((kept >> t) & 1ull) {
+                const int pos = total + __popcll(kept & ((1ull << t) - 1ull));
+                keep_idx[(size_t)b * nmax + pos] = ob[i];
+            }
+            total += __popcll(kept);
+            if (t == 0) kept_s = kept;
+        }
+        __syncthreads();
+        const unsigned long long kept = kept_s;
+        for (int w = c + 1 + t; w < nw; w += 256) {
+            unsigned long long acc = removed[w];
+            unsigned long long k = kept;
+            while (k) {
+                const int j = __ffsll((long long)k) - 1;
+                k &= k - 1;
+                acc |= mb[(size_t)(c * 64 + j) * W + w];
+            }
+            removed[w] = acc;
+        }
+        __syncthreads();
+    }
+    if (t == 0) nkeep[b] = total;
+}
+
+// det row = cand[keep] rescaled like the numpy tail of post_process (bbox.py:145-158)
+__global__ __launch_bounds__(256) void nms_gather_kernel(const float* cand, int A, int nmax, const int* keep_idx, const int* nkeep, const int* image_hw,
+                                                         float* det) {
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nkeep[b]) return;
+    const float* r = cand + ((size_t)b * A + keep_idx[(size_t)b * nmax + k]) * 7;
+    const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+    const float cx = (x1 + x2) / 2, cy = (y1 + y2) / 2;
+    const float w = x2 - x1, h = y2 - y1;
+    const float top = cy - (h / 2.f), left = cx - (w / 2.f), bottom = cy + (h / 2.f), right = cx + (w / 2.f);
+    const double ih = (double)image_hw[b * 2], iw = (double)image_hw[b * 2 + 1];
+    float* d = det + ((size_t)b * nmax + k) * 7;
+    d[0] = (float)((double)top * ih);
+    d[1] = (float)((double)left * iw);
+    d[2] = (float)((double)bottom * ih);
+    d[3] = (float)((double)right * iw);
+    d[4] = r[4]; d[5] = r[5]; d[6] = r[6];
+}
+
+}  // namespace
+
+extern "C" int ccnet_decode(const float* const* head_dev, const int64_t* sb, const int64_t* sc, const int64_t* sp, const int32_t* h, const int32_t* w,
+                            int nlev, int B, int nc, float in_h, float in_w, float* out_dev, ccnet_stream stream) {
+    CC_REQUIRE(head_dev && sb && sc && sp && h && w && out_dev, "decode: null pointer");
+    CC_REQUIRE(nlev > 0 && nlev <= MAXLEV && B > 0 && nc > 0 && in_h > 0 && in_w > 0, "decode: bad sizes (nlev=%d)", nlev);
+    DecodeP p{};
+    int A = 0;
+    for (int l = 0; l < nlev; ++l) {
+        CC_REQUIRE(head_dev[l] && h[l] > 0 && w[l] > 0, "decode: bad level %d", l);
+        p.head[l] = head_dev[l]; p.sb[l] = sb[l]; p.sc[l] = sc[l]; p.sp[l] = sp[l]; p.h[l] = h[l]; p.w[l] = w[l];
+        p.a0[l] = A;
+        // python: input_shape[0] / h is a double, stored into an fp32 tensor by torch.full (bbox.py:57)
+        p.stride[l] = (float)((double)in_h / (double)h[l]);
+        A += h[l] * w[l];
+    }
+    p.a0[nlev] = A;
+    p.nlev = nlev; p.B = B; p.A = A; p.nch = 5 + nc; p.in_h = in_h; p.in_w = in_w; p.out = out_dev;
+    const unsigned blocks = (unsigned)(((long long)B * A + 255) / 256);
+    return ccnet_submit(
+        [p, blocks](hipStream_t st, const float*) -> int {
+            hipLaunchKernelGGL(decode_kernel, dim3(blocks), dim3(256), 0, st, p);
+            CC_LAUNCH_CHECK();
+            return CCNET_OK;
+        },
+        stream);
+}
+
+extern "C" int ccnet_filter(const float* pred_dev, int B, int A, int nc, float conf_thres, float* cand_dev, int32_t* counts_dev,
+                            ccnet_stream stream) {
+    CC_REQUIRE(pred_dev && cand_dev && counts_dev, "filter: null pointer");
+    CC_REQUIRE(B > 0 && B <= 65535 && A > 0 && nc > 0, "filter: bad sizes");
+    return ccnet_submit(
+        [=](hipStream_t st, const float*) -> int {
+            hipLaunchKernelGGL(filter_kernel, dim3(B), dim3(1024), 0, st, pred_dev, A, nc, conf_thres, cand_dev, counts_dev);
+            CC_LAUNCH_CHECK();
+            return CCNET_OK;
+        },
+        stream);
+}
+
+extern "C" size_t ccnet_nms_workspace_bytes(int B, int nmax) {
+    if (B <= 0 || nmax <= 0) return 256;
+    return nms_ws(B, nmax).total;
+}
+
+extern "C" int ccnet_nms(const float* cand_dev, const int32_t* counts_dev, int B, int A, int nmax, double nms_thres, const int32_t* image_hw_dev,
+                         float* det_dev, int32_t* keep_idx_dev, int32_t* nkeep_dev, void* workspace_dev, ccnet_stream stream) {
+    CC_REQUIRE(cand_dev && counts_dev && image_hw_dev && det_dev && keep_idx_dev && nkeep_dev && workspace_dev, "nms: null pointer");
+    CC_REQUIRE(B > 0 && B <= 65535 && A > 0 && nmax > 0 && nmax <= A, "nms: bad sizes (B=%d A=%d nmax=%d)", B, A, nmax);
+    CC_REQUIRE(((uintptr_t)workspace_dev % 256) == 0, "nms: workspace must be 256-byte aligned");
+    const NmsWs ws = nms_ws(B, nmax);
+    CC_REQUIRE(ws.W <= 65535, "nms: nmax too large for one launch (%d)", nmax);
+    CC_REQUIRE((size_t)ws.W * 8 <= 64 * 1024, "nms: nmax too large (%d)", nmax);
+    const int np = ws.W * 64;
+    unsigned char* base = (unsigned char*)workspace_dev;
+    float4* boxes = (float4*)(base + ws.boxes);
+    float4* sboxes = boxes + (size_t)B * np;
+    float* scores = (float*)(base + ws.scores);
+    int* order = (int*)(base + ws.order);
+    unsigned long long* mask = (unsigned long long*)(base + ws.mask);
+    const int W = ws.W;
+    return ccnet_submit(
+        [=](hipStream_t st, const float*) -> int {
+            hipLaunchKernelGGL(nms_prepare_kernel, dim3(B), dim3(256), 0, st, cand_dev, counts_dev, A, np, boxes, scores);
+            hipLaunchKernelGGL(nms_rank_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, st, counts_dev, np, boxes, scores, sboxes, order);
+            hipLaunchKernelGGL(nms_mask_kernel, dim3(W, W, B), dim3(64), 0, st, counts_dev, np, W, sboxes, nms_thres, mask);
+            hipLaunchKernelGGL(nms_sweep_kernel, dim3(B), dim3(256), (size_t)W * 8, st, counts_dev, np, W, mask, order, nmax, keep_idx_dev, nkeep_dev);
+            hipLaunchKernelGGL(nms_gather_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, st, cand_dev, A, nmax, keep_idx_dev, nkeep_dev,
+                               image_hw_dev, det_dev);
+            CC_LAUNCH_CHECK();
+            return CCNET_OK;
+        },
+        stream);
+}

@@ -1,0 +1,363 @@
+// Attention gates: CBAM (channel + spatial), ECA, and the ASFF softmax fusion.  All HBM-bound elementwise /
+// reduction kernels over NHWC; reductions are two-stage and atomic-free, so results are run-to-run identical.
+//
+// CBAM passes (dependency-forced 3 reads + 1 write of x):
+//   1 pool_partial : per (image, pixel chunk) sum and max per channel            -> scratch
+//   2 cbam_mlp     : finish avg/max, shared MLP, sigmoid                          -> ca[B][C]
+//   3 cbam_stats   : per pixel mean_c / max_c of x*ca                             -> stats[B][H][W][2]
+//   4 cbam_apply   : sa = sigmoid(conv kxk(stats)); out = x*ca*sa
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+constexpr int POOL_CHUNK = 1024;  // pixels per partial block
+
+// scratch layout (floats): partial[B][nchunk][2][C] | ca[B][C] | stats[B][H*W][2]
+struct GateScratch {
+    size_t partial, ca, stats, total;
+    int nchunk;
+};
+GateScratch gate_scratch(int B, int H, int W, int C) {
+    GateScratch s;
+    s.nchunk = (H * W + POOL_CHUNK - 1) / POOL_CHUNK;
+    s.partial = 0;
+    s.ca = s.partial + (size_t)B * s.nchunk * 2 * C;
+    s.stats = s.ca + (size_t)B * C;
+    s.total = s.stats + (size_t)B * H * W * 2;
+    s.total = (s.total + 3) & ~(size_t)3;
+    return s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_partial_kernel(const unsigned char* in, int ldc, int coff, int C, int HW, int nchunk, float* partial) {
+    __shared__ float red[2][256][8];
+    const int G = C / 8;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int p0 = chunk * POOL_CHUNK;
+    const int p1 = min(HW, p0 + POOL_CHUNK);
+    const int t = threadIdx.x;
+    for (int g0 = 0; g0 < G; g0 += 256) {
+        const int TG = min(G - g0, 256);
+        const int PL = 256 / TG;
+        const int g = g0 + t % TG, pl = t / TG;
+        float s[8], m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.0f; m[e] = -INFINITY; }
+        if (pl < PL) {
+            for (int p = p0 + pl; p < p1; p += PL) {
+                float v[8];
+                Chan8<T>::load(in + (((size_t)b * HW + p) * ldc + coff + g * 8) * sizeof(T), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += v[e]; m[e] = fmaxf(m[e], v[e]); }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[0][t][e] = s[e]; red[1][t][e] = m[e]; }
+        __syncthreads();
+        if (t < TG) {
+            for (int q = 1; q < PL; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += red[0][t + q * TG][e]; m[e] = fmaxf(m[e], red[1][t + q * TG][e]); }
+            float* dst = partial + (((size_t)b * nchunk + chunk) * 2) * C + g * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dst[e] = s[e]; dst[C + e] = m[e]; }
+        }
+        __syncthreads();
+    }
+}
+
+// one block per image; dynamic LDS: avg[C] max[C] hid[2*Cr]
+__global__ __launch_bounds__(256) void cbam_mlp_kernel(const float* partial, int nchunk, int C, int Cr, int HW, const float* fc1, const float* fc2,
+                                                       float* ca) {
+    extern __shared__ float sm[];
+    float* avg = sm;
+    float* mx = sm + C;
+    float* hid = sm + 2 * C;
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int c = t; c < C; c += 256) {
+        float s = 0.0f, m = -INFINITY;
+        for (int k = 0; k < nchunk; ++k) {
+            const float* src = partial + (((size_t)b * nchunk + k) * 2) * C;
+            s += src[c];
+            m = fmaxf(m, src[C + c]);
+        }
+        avg[c] = s / (float)HW;
+        mx[c] = m;
+    }
+    __syncthreads();
+    const int lane = t & 63, wave = t >> 6;
+    for (int j = wave; j < 2 * Cr; j += 4) {
+        const float* v = (j < Cr) ? avg : mx;
+        const float* wr = fc1 + (size_t)(j < Cr ? j : j - Cr) * C;
+        float a = 0.0f;
+        for (int c = lane; c < C; c += 64) a = fmaf(wr[c], v[c], a);
+        a = wave_sum(a);
+        if (lane == 0) hid[j] = fmaxf(a, 0.0f);
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        const float* wr = fc2 + (size_t)c * Cr;
+        float a = 0.0f, m = 0.0f;
+        for (int j = 0; j < Cr; ++j) { a = fmaf(wr[j], hid[j], a); m = fmaf(wr[j], hid[Cr + j], m); }
+        ca[(size_t)b * C + c] = sigmoidf_(a + m);
+    }
+}
+
+// LP lanes cooperate on one pixel (LP = power of two >= C/8, at most 64)
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_stats_kernel(const unsigned char* in, int ldc, int coff, int C, int HW, long long npix, int LP,
+                                                         const float* ca, float* stats) {
+    const int G = C / 8;
+    const int t = threadIdx.x;
+    const int sub = t % LP;
+    const long long pix = ((long long)blockIdx.x * 256 + t) / LP;
+    const bool live = pix < npix;
+    const int b = live ? (int)(pix / HW) : 0;
+    float s = 0.0f, m = -INFINITY;
+    if (live) {
+        for (int g = sub; g < G; g += LP) {
+            float v[8];
+            Chan8<T>::load(in + ((size_t)pix * ldc + coff + g * 8) * sizeof(T), v);
+            const float* cg = ca + (size_t)b * C + g * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = v[e] * cg[e];
+                s += x;
+                m = fmaxf(m, x);
+            }
+        }
+    }
+    for (int o = LP >> 1; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        m = fmaxf(m, __shfl_xor(m, o, 64));
+    }
+    if (live && sub == 0) {
+        stats[pix * 2] = s / (float)C;
+        stats[pix * 2 + 1] = m;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_apply_kernel(const unsigned char* in, int ldc, int coff, int C, int H, int W, long long npix, int LP,
+                                                         const float* ca, const float* stats, const float* wk, int k, unsigned char* out,
+                                                         int out_ldc, int out_coff) {
+    const int G = C / 8;
+    const int t = threadIdx.x;
+    const int sub = t % LP;
+    const long long pix = ((long long)blockIdx.x * 256 + t) / LP;
+    const bool live = pix < npix;
+    const int HW = H * W;
+    float a = 0.0f;
+    int b = 0;
+    if (live) {
+        b = (int)(pix / HW);
+        const int r = (int)(pix - (long long)b * HW);
+        const int y = r / W, x = r - y * W;
+        const int pad = k / 2, kk = k * k;
+        for (int tap = sub; tap < kk; tap += LP) {
+            const int ky = tap / k, kx = tap - ky * k;
+            const int iy = y + ky - pad, ix = x + kx - pad;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                const float* sp = stats + (((size_t)b * H + iy) * W + ix) * 2;
+                a = fmaf(wk[tap], sp[0], a);
+                a = fmaf(wk[kk + tap], sp[1], a);
+            }
+        }
+    }
+    for (int o = LP >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (!live) return;
+    const float sa = sigmoidf_(a);
+    for (int g = sub; g < G; g += LP) {
+        float v[8];
+        Chan8<T>::load(in + ((size_t)pix * ldc + coff + g * 8) * sizeof(T), v);
+        const float* cg = ca + (size_t)b * C + g * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] * cg[e]) * sa;
+        Chan8<T>::store(out + ((size_t)pix * out_ldc + out_coff + g * 8) * sizeof(T), v);
+    }
+}
+
+// ECA gate: avg over pixels -> 3-tap conv over the channel axis (zero padded) -> sigmoid
+__global__ __launch_bounds__(256) void eca_gate_kernel(const float* partial, int nchunk, int C, int HW, const float* w3, float* gate) {
+    extern __shared__ float avg[];
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int c = t; c < C; c += 256) {
+        float s = 0.0f;
+        for (int k = 0; k < nchunk; ++k) s += partial[(((size_t)b * nchunk + k) * 2) * C + c];
+        avg[c] = s / (float)HW;
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        float l = c > 0 ? avg[c - 1] : 0.0f, r = c + 1 < C ? avg[c + 1] : 0.0f;
+        gate[(size_t)b * C + c] = sigmoidf_(w3[0] * l + w3[1] * avg[c] + w3[2] * r);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(const unsigned char* in, int ldc, int coff, int C, int HW, long long total,
+                                                    const float* gate, unsigned char* out, int out_ldc, int out_coff) {
+    const int G = C / 8;
+    long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % G);
+    const long long pix = idx / G;
+    const int b = (int)(pix / HW);
+    float v[8];
+    Chan8<T>::load(in + ((size_t)pix * ldc + coff + g * 8) * sizeof(T), v);
+    const float* cg = gate + (size_t)b * C + g * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= cg[e];
+    Chan8<T>::store(out + ((size_t)pix * out_ldc + out_coff + g * 8) * sizeof(T), v);
+}
+
+struct SrcP {
+    const unsigned char* ptr;
+    int ldc, coff, shift;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void asff_fuse_kernel(SrcP s0, SrcP s1, SrcP s2, const unsigned char* logit, int l_ldc, int l_coff, int C, int H,
+                                                        int W, long long total, unsigned char* out, int out_ldc, int out_coff) {
+    const int G = C / 8;
+    long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % G);
+    const long long pix = idx / G;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int b = (int)(pix / ((long long)W * H));
+    const T* lp = (const T*)(logit + ((size_t)pix * l_ldc + l_coff) * sizeof(T));
+    float a0 = load1<T>(lp), a1 = load1<T>(lp + 1), a2 = load1<T>(lp + 2);
+    float mx = fmaxf(a0, fmaxf(a1, a2));
+    float e0 = __expf(a0 - mx), e1 = __expf(a1 - mx), e2 = __expf(a2 - mx);
+    float inv = 1.0f / (e0 + e1 + e2);
+    float w[3] = {e0 * inv, e1 * inv, e2 * inv};
+    const SrcP* src[3] = {&s0, &s1, &s2};
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const SrcP& s = *src[k];
+        size_t sp = ((size_t)b * (H >> s.shift) + (y >> s.shift)) * (W >> s.shift) + (x >> s.shift);
+        float v[8];
+        Chan8<T>::load(s.ptr + (sp * s.ldc + s.coff + g * 8) * sizeof(T), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e] * w[k];
+    }
+    Chan8<T>::store(out + ((size_t)pix * out_ldc + out_coff + g * 8) * sizeof(T), acc);
+}
+
+bool slice8_ok(const ccnet_slice& s, int dtype) {
+    return cc_slice_vec_ok(s, dtype) && (s.ldc % 8) == 0 && (s.coff % 8) == 0 && (s.C % 8) == 0;
+}
+int lanes_per_pixel(int C) {
+    int g = C / 8, lp = 1;
+    while (lp < g && lp < 64) lp <<= 1;
+    return lp;
+}
+
+}  // namespace
+
+extern "C" size_t ccnet_gate_scratch_floats(int B, int H, int W, int C) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    return gate_scratch(B, H, W, C).total;
+}
+
+extern "C" int ccnet_cbam(ccnet_slice in, int dtype, int B, int H, int W, const float* fc1, const float* fc2, int Cr, const float* w7, int k7,
+                          float* scratch_dev, ccnet_slice out, ccnet_stream stream) {
+    CC_REQUIRE(cc_dtype_ok(dtype) && slice8_ok(in, dtype) && slice8_ok(out, dtype) && in.C == out.C && in.shift == 0 && out.shift == 0,
+               "cbam: bad slices");
+    CC_REQUIRE(fc1 && fc2 && w7 && scratch_dev && Cr > 0 && (k7 == 7 || k7 == 3), "cbam: bad weights (Cr=%d k=%d)", Cr, k7);
+    CC_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && (long long)B * H * W < (1ll << 31), "cbam: bad geometry");
+    const int C = in.C, HW = H * W;
+    const GateScratch gs = gate_scratch(B, H, W, C);
+    const long long npix = (long long)B * HW;
+    const int LP = lanes_per_pixel(C);
+    const unsigned pblocks = (unsigned)((npix * LP + 255) / 256);
+    return ccnet_submit(
+        [=](hipStream_t st, const float*) -> int {
+            float* partial = scratch_dev + gs.partial;
+            float* ca = scratch_dev + gs.ca;
+            float* stats = scratch_dev + gs.stats;
+            const unsigned char* ip = (const unsigned char*)in.ptr;
+            unsigned char* op = (unsigned char*)out.ptr;
+            size_t mlp_lds = (size_t)(2 * C + 2 * Cr) * sizeof(float);
+            if (dtype == CCNET_BF16) {
+                hipLaunchKernelGGL(pool_partial_kernel<__bf16>, dim3(gs.nchunk, B), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, gs.nchunk, partial);
+                hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(256), mlp_lds, st, partial, gs.nchunk, C, Cr, HW, fc1, fc2, ca);
+                hipLaunchKernelGGL(cbam_stats_kernel<__bf16>, dim3(pblocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, npix, LP, ca, stats);
+                hipLaunchKernelGGL(cbam_apply_kernel<__bf16>, dim3(pblocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, H, W, npix, LP, ca, stats, w7,
+                                   k7, op, out.ldc, out.coff);
+            } else {
+                hipLaunchKernelGGL(pool_partial_kernel<float>, dim3(gs.nchunk, B), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, gs.nchunk, partial);
+                hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(256), mlp_lds, st, partial, gs.nchunk, C, Cr, HW, fc1, fc2, ca);
+                hipLaunchKernelGGL(cbam_stats_kernel<float>, dim3(pblocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, npix, LP, ca, stats);
+                hipLaunchKernelGGL(cbam_apply_kernel<float>, dim3(pblocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, H, W, npix, LP, ca, stats, w7,
+                                   k7, op, out.ldc, out.coff);
+            }
+            CC_LAUNCH_CHECK();
+            return CCNET_OK;
+        },
+        stream);
+}
+
+extern "C" int ccnet_eca(ccnet_slice in, int dtype, int B, int H, int W, const float* w3, float* scratch_dev, ccnet_slice out,
+                         ccnet_stream stream) {
+    CC_REQUIRE(cc_dtype_ok(dtype) && slice8_ok(in, dtype) && slice8_ok(out, dtype) && in.C == out.C && in.shift == 0 && out.shift == 0,
+               "eca: bad slices");
+    CC_REQUIRE(w3 && scratch_dev, "eca: null pointer");
+    CC_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && (long long)B * H * W < (1ll << 31), "eca: bad geometry");
+    const int C = in.C, HW = H * W;
+    const GateScratch gs = gate_scratch(B, H, W, C);
+    const long long total = (long long)B * HW * (C / 8);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    return ccnet_submit(
+        [=](hipStream_t st, const float*) -> int {
+            float* partial = scratch_dev + gs.partial;
+            float* gate = scratch_dev + gs.ca;
+            const unsigned char* ip = (const unsigned char*)in.ptr;
+            unsigned char* op = (unsigned char*)out.ptr;
+            if (dtype == CCNET_BF16) {
+                hipLaunchKernelGGL(pool_partial_kernel<__bf16>, dim3(gs.nchunk, B), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, gs.nchunk, partial);
+                hipLaunchKernelGGL(eca_gate_kernel, dim3(B), dim3(256), C * sizeof(float), st, partial, gs.nchunk, C, HW, w3, gate);
+                hipLaunchKernelGGL(scale_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, total, gate, op, out.ldc, out.coff);
+            } else {
+                hipLaunchKernelGGL(pool_partial_kernel<float>, dim3(gs.nchunk, B), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, gs.nchunk, partial);
+                hipLaunchKernelGGL(eca_gate_kernel, dim3(B), dim3(256), C * sizeof(float), st, partial, gs.nchunk, C, HW, w3, gate);
+                hipLaunchKernelGGL(scale_kernel<float>, dim3(blocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, total, gate, op, out.ldc, out.coff);
+            }
+            CC_LAUNCH_CHECK();
+            return CCNET_OK;
+        },
+        stream);
+}
+
+extern "C" int ccnet_asff_fuse(ccnet_slice l0, ccnet_slice l1, ccnet_slice l2, ccnet_slice logits, int dtype, int B, int H, int W, ccnet_slice out,
+                               ccnet_stream stream) {
+    CC_REQUIRE(cc_dtype_ok(dtype) && slice8_ok(l0, dtype) && slice8_ok(l1, dtype) && slice8_ok(l2, dtype) && slice8_ok(out, dtype) && out.shift == 0,
+               "asff_fuse: bad slices");
+    CC_REQUIRE(l0.C == out.C && l1.C == out.C && l2.C == out.C, "asff_fuse: channel mismatch");
+    CC_REQUIRE(logits.ptr && logits.C == 3 && logits.shift == 0 && logits.ldc >= logits.coff + 3, "asff_fuse: logits slice must have 3 channels");
+    CC_REQUIRE(B > 0 && H > 0 && W > 0, "asff_fuse: bad geometry");
+    const ccnet_slice* ls[3] = {&l0, &l1, &l2};
+    for (int k = 0; k < 3; ++k)
+        CC_REQUIRE((H % (1 << ls[k]->shift)) == 0 && (W % (1 << ls[k]->shift)) == 0, "asff_fuse: H,W not divisible by upsampling factor");
+    const long long total = (long long)B * H * W * (out.C / 8);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    SrcP s0{(const unsigned char*)l0.ptr, l0.ldc, l0.coff, l0.shift}, s1{(const unsigned char*)l1.ptr, l1.ldc, l1.coff, l1.shift},
+        s2{(const unsigned char*)l2.ptr, l2.ldc, l2.coff, l2.shift};
+    return ccnet_submit(
+        [=](hipStream_t st, const float*) -> int {
+            if (dtype == CCNET_BF16)
+                hipLaunchKernelGGL(asff_fuse_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, s0, s1, s2, (const unsigned char*)logits.ptr, logits.ldc,
+                                   logits.coff, out.C, H, W, total, (unsigned char*)out.ptr, out.ldc, out.coff);
+            else
+                hipLaunchKernelGGL(asff_fuse_kernel<float>, dim3(blocks), dim3(256), 0, st, s0, s1, s2, (const unsigned char*)logits.ptr, logits.ldc,
+                                   logits.coff, out.C, H, W, total, (unsigned char*)out.ptr, out.ldc, out.coff);
+            CC_LAUNCH_CHECK();
+            return CCNET_OK;
+        },
+        stream);
+}

@@ -1,0 +1,210 @@
+"""Host-side operator layer: weight folding/packing (fp64 on the CPU) and thin wrappers that hand NHWC device
+buffers to the C ABI.  Every wrapper either launches on torch's current stream or, inside `Recorder`, appends to
+a plan.  No compute happens in Python/ATen here."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT, BF16, F32, ConvDesc, Slice, check, lib, null_slice, sl, stream_ptr
+
+BN_EPS = 1e-5
+
+
+# --------------------------------------------------------------------------------------------- weight packing
+def fold_bn(w, bn=None, conv_bias=None, eps=BN_EPS):
+    """(weight OIHW any float, bn = (gamma, beta, mean, var) or None, conv bias or None) -> (w fp64, b fp64).
+    BaseConv = conv(no bias) -> BN(eval) (network/model_block.py:52-58)."""
+    w = w.detach().to("cpu", torch.float64)
+    cout = w.shape[0]
+    b = torch.zeros(cout, dtype=torch.float64) if conv_bias is None else conv_bias.detach().to("cpu", torch.float64).clone()
+    if bn is not None:
+        g, beta, mean, var = [t.detach().to("cpu", torch.float64) for t in bn]
+        s = g / torch.sqrt(var + eps)
+        w = w * s.view(-1, *([1] * (w.dim() - 1)))
+        b = (b - mean) * s + beta
+    return w, b
+
+
+def s2d_to_6x6(w3):
+    """SpaceToDepth (TL,TR,BL,BR concat, model_block.py:169-173) + k3 s1 p1 conv == k6 s2 p2 conv on the original
+    tensor with W6[o, c, 2u+dy, 2v+dx] = W3[o, (2dy+dx)*C + c, u, v]."""
+    co, c4, kh, kw = w3.shape
+    assert kh == 3 and kw == 3 and c4 % 4 == 0
+    c = c4 // 4
+    w6 = torch.zeros(co, c, 6, 6, dtype=w3.dtype)
+    for dy in range(2):
+        for dx in range(2):
+            w6[:, :, dy::2, dx::2] = w3[:, (2 * dy + dx) * c:(2 * dy + dx + 1) * c]
+    return w6
+
+
+class PackedConv:
+    """Device-resident packed weights of one conv: [Cout_pad][Kpad] in `dtype`, fp32 bias."""
+
+    def __init__(self, w, b, dtype, device):
+        w = w.to(torch.float64)
+        cout, cin, kh, kw = w.shape
+        self.cout, self.cin, self.kh, self.kw, self.dtype = cout, cin, kh, kw, dtype
+        k = kh * kw * cin
+        self.cout_pad, self.kpad = _lib.conv_pack_dims(dtype, cout, k)
+        packed = torch.zeros(self.cout_pad, self.kpad, dtype=torch.float64)
+        packed[:cout, :k] = w.permute(0, 2, 3, 1).reshape(cout, k)
+        self.weight = packed.to(_lib.torch_dtype(dtype)).to(device).contiguous()
+        self.bias = None if b is None else b.to(torch.float32).to(device).contiguous()
+
+
+def pack_stem(w6, b, device):
+    """[Cout][3][6][6] -> fp32 [Cout][160], k = (c*6 + ky)*8 + kx (include/ccnet_hip.h: ccnet_stem_conv)."""
+    cout = w6.shape[0]
+    assert tuple(w6.shape[1:]) == (3, 6, 6)
+    p = torch.zeros(cout, 20, 8, dtype=torch.float64)
+    p[:, :18, :6] = w6.to(torch.float64).reshape(cout, 18, 6)
+    return p.reshape(cout, 160).to(torch.float32).to(device).contiguous(), b.to(torch.float32).to(device).contiguous()
+
+
+# --------------------------------------------------------------------------------------------- op wrappers
+def conv2d(ins, pc, B, H, W, stride, pad, out, act="none", residual=None, out_dtype=None):
+    """ins: list of 1-2 Slice (channel concat); out/residual: Slice.  H, W: logical input size."""
+    d = ConvDesc()
+    d.dtype = pc.dtype
+    d.out_dtype = pc.dtype if out_dtype is None else out_dtype
+    d.B, d.H, d.W = B, H, W
+    d.kh, d.kw, d.stride, d.pad = pc.kh, pc.kw, stride, pad
+    d.Ho = (H + 2 * pad - pc.kh) // stride + 1
+    d.Wo = (W + 2 * pad - pc.kw) // stride + 1
+    d.Cout = pc.cout
+    d.nseg = len(ins)
+    for i, s in enumerate(ins):
+        d.inp[i] = s
+    if sum(s.C for s in ins) != pc.cin:
+        raise ValueError("conv2d: input slices carry %d channels, weights expect %d" % (sum(s.C for s in ins), pc.cin))
+    d.weight = pc.weight.data_ptr()
+    d.Kpad, d.Cout_pad = pc.kpad, pc.cout_pad
+    d.bias = None if pc.bias is None else pc.bias.data_ptr()
+    d.act = ACT[act]
+    d.residual = null_slice() if residual is None else residual
+    d.out = out
+    check(lib().ccnet_conv2d(C.byref(d), stream_ptr()))
+    return d.Ho, d.Wo
+
+
+def stem_conv(x, w, b, cout, act, out, out_dtype):
+    B, _, H, W = x.shape
+    check(lib().ccnet_stem_conv(x.data_ptr(), B, H, W, w.data_ptr(), b.data_ptr(), cout, ACT[act], out, out_dtype, stream_ptr()))
+
+
+def dwconv3x3(inp, dtype, B, H, W, w, b, out):
+    check(lib().ccnet_dwconv3x3(inp, dtype, B, H, W, w.data_ptr(), b.data_ptr(), out, stream_ptr()))
+
+
+def sppf_pool(buf, dtype, B, H, W):
+    check(lib().ccnet_sppf_pool(buf, dtype, B, H, W, stream_ptr()))
+
+
+def maxpool3x3s2(inp, dtype, B, H, W, out):
+    check(lib().ccnet_maxpool3x3s2(inp, dtype, B, H, W, out, stream_ptr()))
+
+
+def gate_scratch_floats(B, H, W, Cc):
+    return int(lib().ccnet_gate_scratch_floats(B, H, W, Cc))
+
+
+def cbam(inp, dtype, B, H, W, fc1, fc2, w7, scratch, out):
+    cr = fc1.shape[0]
+    k = w7.shape[-1]
+    check(lib().ccnet_cbam(inp, dtype, B, H, W, fc1.data_ptr(), fc2.data_ptr(), cr, w7.data_ptr(), k, scratch.data_ptr(), out, stream_ptr()))
+
+
+def eca(inp, dtype, B, H, W, w3, scratch, out):
+    check(lib().ccnet_eca(inp, dtype, B, H, W, w3.data_ptr(), scratch.data_ptr(), out, stream_ptr()))
+
+
+def asff_fuse(l0, l1, l2, logits, dtype, B, H, W, out):
+    check(lib().ccnet_asff_fuse(l0, l1, l2, logits, dtype, B, H, W, out, stream_ptr()))
+
+
+def layernorm(x, res, gamma, beta, out, dtype, rows, E, eps=1e-5):
+    check(lib().ccnet_layernorm(x.data_ptr(), None if res is None else res.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                out.data_ptr(), dtype, rows, E, eps, stream_ptr()))
+
+
+def attention(q, k, v, dtype, Sq, Sk, N, heads, hd, out):
+    check(lib().ccnet_attention(q, k, v, dtype, Sq, Sk, N, heads, hd, out, stream_ptr()))
+
+
+def decode(heads, nc, in_h, in_w, out):
+    """heads: list of fp32 CUDA tensors viewed as (B, 5+nc, h, w) with arbitrary strides over (b, c) and a uniform
+    pixel stride (NCHW contiguous or an NHWC buffer permuted to NCHW)."""
+    n = len(heads)
+    B = heads[0].shape[0]
+    ptrs = (C.c_void_p * n)(*[h.data_ptr() for h in heads])
+    sb = (C.c_int64 * n)()
+    sc = (C.c_int64 * n)()
+    sp = (C.c_int64 * n)()
+    hh = (C.c_int32 * n)()
+    ww = (C.c_int32 * n)()
+    for i, h in enumerate(heads):
+        if h.dtype != torch.float32 or h.dim() != 4 or h.shape[1] != 5 + nc:
+            raise ValueError("decode: head %d must be fp32 (B,%d,h,w)" % (i, 5 + nc))
+        st = h.stride()
+        if st[2] != h.shape[3] * st[3]:
+            raise ValueError("decode: head %d rows are not uniformly strided" % i)
+        sb[i], sc[i], sp[i] = st[0], st[1], st[3]
+        hh[i], ww[i] = h.shape[2], h.shape[3]
+    check(lib().ccnet_decode(ptrs, sb, sc, sp, hh, ww, n, B, nc, float(in_h), float(in_w), out.data_ptr(), stream_ptr()))
+
+
+def filter_candidates(pred, nc, conf, cand, counts):
+    B, A, _ = pred.shape
+    check(lib().ccnet_filter(pred.data_ptr(), B, A, nc, float(np.float32(conf)), cand.data_ptr(), counts.data_ptr(), stream_ptr()))
+
+
+def nms_workspace_bytes(B, nmax):
+    return int(lib().ccnet_nms_workspace_bytes(B, nmax))
+
+
+def nms(cand, counts, nmax, thr, image_hw, det, keep_idx, nkeep, workspace):
+    B, A, _ = cand.shape
+    check(lib().ccnet_nms(cand.data_ptr(), counts.data_ptr(), B, A, nmax, float(thr), image_hw.data_ptr(), det.data_ptr(),
+                          keep_idx.data_ptr(), nkeep.data_ptr(), workspace.data_ptr(), stream_ptr()))
+
+
+class Recorder:
+    """with Recorder() as r: ...op wrappers...  -> r.plan is a replayable ccnet_plan handle."""
+
+    def __init__(self):
+        self.handle = C.c_void_p()
+
+    def __enter__(self):
+        check(lib().ccnet_plan_begin(C.byref(self.handle)))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        lib().ccnet_plan_end()
+        if et is not None:
+            lib().ccnet_plan_destroy(self.handle)
+            self.handle = C.c_void_p()
+        return False
+
+
+class Plan:
+    def __init__(self, handle, keepalive):
+        self.handle = handle
+        self.keepalive = keepalive  # tensors whose device pointers the plan has baked in
+
+    @property
+    def num_ops(self):
+        return lib().ccnet_plan_num_ops(self.handle)
+
+    def run(self, x=None):
+        check(lib().ccnet_plan_run(self.handle, None if x is None else x.data_ptr(), stream_ptr()))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().ccnet_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

@@ -1,0 +1,94 @@
+"""Drop-in for the reference's utils/bbox.py: decode_outputs (utils/bbox.py:13-79) and post_process
+(utils/bbox.py:82-159) with the same signatures and return types, computed by libccnet_hip.so on the GPU.
+
+Differences a caller can observe (documented in DESIGN.md):
+  * decode_outputs returns a contiguous (B, A, 5+nc) tensor (the reference returns a permuted view of the same values);
+  * post_process does not overwrite prediction[:, :, :4] with corner boxes (the reference does, as a side effect);
+  * there is one device->host sync per batch (the candidate counts), not one per image.
+NMS follows torchvision 0.9.0 `batched_nms` (coordinate trick) with a stable descending sort; keep order and
+indices are bit-exact against the oracle's scalar restatement.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+
+
+def _require_cuda(t, what):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("ccnet_amd.%s needs CUDA (ROCm) tensors; this build has no CPU path" % what)
+
+
+def decode_outputs(outputs, input_shape):
+    """outputs: list of (B, 5+nc, h_k, w_k) fp32 CUDA tensors (any b/c strides); input_shape = [in_h, in_w].
+    Returns (B, sum h_k*w_k, 5+nc): [cx, cy, w, h] normalised, obj and class probabilities."""
+    outputs = list(outputs)
+    for o in outputs:
+        _require_cuda(o, "decode_outputs")
+    heads = []
+    for o in outputs:
+        o = o.float()
+        if o.stride(2) != o.shape[3] * o.stride(3):
+            o = o.contiguous()
+        heads.append(o)
+    B, nch = heads[0].shape[0], heads[0].shape[1]
+    A = sum(int(h.shape[2]) * int(h.shape[3]) for h in heads)
+    out = torch.empty(B, A, nch, dtype=torch.float32, device=heads[0].device)
+    if B * A:
+        ops.decode(heads, nch - 5, input_shape[0], input_shape[1], out)
+    return out
+
+
+def _filter_and_nms(pred, num_classes, conf_thres, nms_thres, image_hw):
+    """pred (B, A, 5+nc) fp32 CUDA contiguous.  Returns (det (B,nmax,7), keep_idx (B,nmax), nkeep (B,), counts (B,)) on device,
+    after ONE host sync to size the NMS workspace."""
+    B, A, _ = pred.shape
+    dev = pred.device
+    cand = torch.empty(B, A, 7, dtype=torch.float32, device=dev)
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    ops.filter_candidates(pred, num_classes, conf_thres, cand, counts)
+    nmax = int(counts.max().item())  # the one sync
+    nmax = max(nmax, 1)
+    return (cand, counts) + _nms(cand, counts, nmax, nms_thres, image_hw)
+
+
+def _nms(cand, counts, nmax, nms_thres, image_hw):
+    B = cand.shape[0]
+    dev = cand.device
+    ws = torch.empty(ops.nms_workspace_bytes(B, nmax) + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    ws = ws[off:]
+    det = torch.empty(B, nmax, 7, dtype=torch.float32, device=dev)
+    keep_idx = torch.empty(B, nmax, dtype=torch.int32, device=dev)
+    nkeep = torch.empty(B, dtype=torch.int32, device=dev)
+    ops.nms(cand, counts, nmax, nms_thres, image_hw, det, keep_idx, nkeep, ws)
+    return det, keep_idx, nkeep
+
+
+def nms_keep_indices(cand, counts, nms_thres):
+    """cand (B, A, 7) rows [x1,y1,x2,y2,obj,cls_conf,cls_id], counts (B,) int32: per-image kept indices (score order)."""
+    _require_cuda(cand, "nms_keep_indices")
+    B = cand.shape[0]
+    cand = cand.float().contiguous()
+    nmax = max(int(counts.max().item()), 1) if counts.numel() else 1
+    hw = torch.ones(B, 2, dtype=torch.int32, device=cand.device)
+    det, keep_idx, nkeep = _nms(cand, counts.to(torch.int32).contiguous(), nmax, nms_thres, hw)
+    nk = nkeep.cpu().numpy()
+    ki = keep_idx.cpu().numpy()
+    return [ki[b, :nk[b]].astype(np.int64) for b in range(B)]
+
+
+def post_process(prediction, num_classes, input_shape, image_info, conf_thres=0.5, nms_thres=0.4):
+    """Same contract as the reference: list (len B) of float32 arrays (n_i, 7) with columns
+    [top, left, bottom, right, obj_conf, class_conf, class_id] in original-image pixels; (0,7) when nothing survives;
+    None entries only when there are no anchors at all.  image_info[i] = [name, image_w, image_h] (tools/demo.py:52)."""
+    _require_cuda(prediction, "post_process")
+    B, A = int(prediction.shape[0]), int(prediction.shape[1])
+    if A == 0 or B == 0:
+        return [None for _ in range(B)]
+    pred = prediction.float().contiguous()
+    hw = torch.tensor([[int(image_info[i][2]), int(image_info[i][1])] for i in range(B)], dtype=torch.int32).to(pred.device)
+    cand, counts, det, keep_idx, nkeep = _filter_and_nms(pred, num_classes, conf_thres, nms_thres, hw)
+    nk = nkeep.cpu().numpy()
+    det_h = det.cpu().numpy()
+    return [det_h[b, :nk[b]].copy() for b in range(B)]

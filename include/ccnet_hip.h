@@ -1,0 +1,163 @@
+/* ccnet_hip.h -- C ABI of libccnet_hip.so, the MI355X (gfx950) compute library under the CCNet Python API.
+ *
+ * The reference (ICtrlCV/CCNet) is pure Python on torch/torchvision and has no FFI of its own; each entry
+ * point below names the reference code it stands in for (paths relative to the reference repo root).
+ * The Python host (ccnet_amd/) binds these with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C types only; every pointer named *_dev / inside a ccnet_slice is DEVICE memory owned by the
+ *     caller (PyTorch's allocator in our host); the library allocates no device memory of its own;
+ *   - every launch goes to the caller's stream (hipStream_t passed as void*), nothing synchronises
+ *     unless its comment says so;
+ *   - return 0 on success, a negative CCNET_E* code on failure; ccnet_last_error() gives the thread-local
+ *     message.  Nothing throws or aborts.  Arguments are validated on the host BEFORE any launch.
+ *   - activations are NHWC; a ccnet_slice is a channel range of a [B][H][W][ldc] buffer, so torch.cat on
+ *     channels never copies (producers write their slice of the consumer's buffer).
+ */
+#ifndef CCNET_HIP_H
+#define CCNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ccnet_stream; /* hipStream_t */
+
+enum { CCNET_F32 = 0, CCNET_BF16 = 1 };
+/* network/model_block.py:14-34 get_activation_function */
+enum { CCNET_ACT_NONE = 0, CCNET_ACT_SILU = 1, CCNET_ACT_RELU = 2, CCNET_ACT_RELU6 = 3, CCNET_ACT_LRELU = 4 };
+enum {
+    CCNET_OK = 0,
+    CCNET_EINVAL = -1,  /* bad argument / shape the kernels do not support */
+    CCNET_EHIP = -2,    /* a HIP runtime call failed */
+    CCNET_ENOGPU = -3
+};
+
+typedef struct {
+    void* ptr;     /* element (b=0, y=0, x=0, channel 0) of the WHOLE buffer */
+    int32_t ldc;   /* channels of the whole buffer = pixel stride in elements */
+    int32_t coff;  /* first channel of this slice */
+    int32_t C;     /* channels in this slice */
+    int32_t shift; /* nearest-neighbour upsampling by 2^shift: logical pixel (y,x) is stored pixel (y>>shift, x>>shift)
+                      (nn.Upsample(scale_factor=2, mode="nearest"), network/net.py:103; F.interpolate x2/x4,
+                      network/model_block.py:385-392).  Only read operands may have shift != 0. */
+} ccnet_slice;
+
+const char* ccnet_last_error(void);
+int ccnet_version(void);
+/* number of visible HIP devices (0 when there is no GPU); never fails */
+int ccnet_device_count(void);
+
+/* ---- Conv-BN-act as BN-folded NHWC implicit GEMM on MFMA ------------------------------------------------
+ * Replaces BaseConv.forward (network/model_block.py:57-58), FocusReplaceConv/ASFFConv.forward (:186-187,
+ * :318-319), the SpaceToDepth slice+cat+conv (:166-175; expressed as its exact 6x6 stride-2 pad-2 form),
+ * the bare nn.Conv2d/nn.Linear calls of MobileViT / nn.Transformer / the head preds (:265-277,
+ * network/net.py:178-192), and torch.cat / nn.Upsample on its input side (network/net.py:208-210).
+ *   out[b,oy,ox,n] = act( bias[n] + sum_{ky,kx,c} in[b, oy*stride-pad+ky, ox*stride-pad+kx, c] * W[n][ky][kx][c] ) (+ residual)
+ * in = channel concat of in[0..nseg-1]; zero padding outside the image.
+ * weight: [Cout_pad][Kpad] row-major in `dtype`, K index = (ky*kw + kx)*Ctot + c, zero padded; pad sizes from
+ * ccnet_conv_pack_dims.  bias: fp32[Cout] or NULL.  residual (ptr may be NULL) is added AFTER the activation
+ * (Bottleneck.forward, model_block.py:213-218) and may alias `out`. */
+typedef struct {
+    int32_t dtype;     /* storage type of in / weight / residual: CCNET_F32 or CCNET_BF16; accumulation is fp32 */
+    int32_t out_dtype; /* CCNET_F32 or CCNET_BF16 (fp32 out from bf16 in is used for the head logits) */
+    int32_t B, H, W;   /* logical input size (after `shift`) */
+    int32_t kh, kw, stride, pad;
+    int32_t Ho, Wo, Cout;
+    int32_t nseg;      /* 1 or 2 */
+    ccnet_slice in[2];
+    const void* weight;
+    int32_t Kpad, Cout_pad;
+    const float* bias;
+    int32_t act;
+    ccnet_slice residual;
+    ccnet_slice out;
+} ccnet_conv_desc;
+
+int ccnet_conv_pack_dims(int dtype, int Cout, int K, int* Cout_pad, int* Kpad);
+int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream);
+
+/* ---- network stem: 6x6 stride-2 pad-2 conv on the NCHW fp32 image, folded BN, activation ------------------
+ * Replaces FocusReplaceConv (network/net_deploy.py:41) and SpaceToDepth(3,..)+BaseConv k3 (network/net.py:40)
+ * in its 6x6 form.  x_dev: fp32 [B][3][H][W] (the tensor the reference's callers build, tools/demo.py:56-65).
+ * weight: fp32 [Cout][160] with k = (c*6 + ky)*8 + kx (kx 6,7 and rows 18,19 zero).  Cout must be <= 64 and % 16 == 0. */
+int ccnet_stem_conv(const float* x_dev, int B, int H, int W, const float* weight, const float* bias, int Cout,
+                    int act, ccnet_slice out, int out_dtype, ccnet_stream stream);
+
+/* depthwise 3x3 stride-1 pad-1 with bias, no activation: MobileViT.conv1 (network/model_block.py:265-266).
+ * weight fp32 [9][C] (tap-major), bias fp32 [C]. */
+int ccnet_dwconv3x3(ccnet_slice in, int dtype, int B, int H, int W, const float* weight, const float* bias,
+                    ccnet_slice out, ccnet_stream stream);
+
+/* ---- pooling ---------------------------------------------------------------------------------------------
+ * SPPFBottleneck's three cascaded MaxPool2d(5,1,2) (network/model_block.py:75-81) == windows 5/9/13 of x:
+ * reads channels [coff, coff+C) of buf and writes y1,y2,y3 to [coff+C, coff+4C) of the same buffer. */
+int ccnet_sppf_pool(ccnet_slice buf, int dtype, int B, int H, int W, ccnet_stream stream);
+/* F.max_pool2d(x, 3, stride=2, padding=1) (network/model_block.py:381) */
+int ccnet_maxpool3x3s2(ccnet_slice in, int dtype, int B, int H, int W, ccnet_slice out, ccnet_stream stream);
+
+/* ---- attention gates -------------------------------------------------------------------------------------
+ * CBAM.forward (network/attention_block.py:19-22): x*ca then *sa.  fc1: fp32 [C/r][C], fc2: fp32 [C][C/r],
+ * w7: fp32 [2][k][k] (avg plane first), k = 7 or 3.  scratch_dev: fp32, ccnet_gate_scratch_floats(B,H,W,C) floats. */
+size_t ccnet_gate_scratch_floats(int B, int H, int W, int C);
+int ccnet_cbam(ccnet_slice in, int dtype, int B, int H, int W, const float* fc1, const float* fc2, int Cr,
+               const float* w7, int k7, float* scratch_dev, ccnet_slice out, ccnet_stream stream);
+/* ECA.forward (network/attention_block.py:95-102): global avg -> Conv1d(1,1,3,pad 1) over channels -> sigmoid -> scale */
+int ccnet_eca(ccnet_slice in, int dtype, int B, int H, int W, const float* w3, float* scratch_dev, ccnet_slice out,
+              ccnet_stream stream);
+/* ASFF fusion (network/model_block.py:401-405): softmax over the 3 weight logits (fp32/bf16 [B][H][W][ldc], 3 ch)
+ * and the weighted sum of the three resized levels (each may carry an upsampling shift). */
+int ccnet_asff_fuse(ccnet_slice l0, ccnet_slice l1, ccnet_slice l2, ccnet_slice logits, int dtype, int B, int H, int W,
+                    ccnet_slice out, ccnet_stream stream);
+
+/* ---- Transformer pieces (torch.nn.Transformer as used by MobileViT, network/model_block.py:270-271,290) ----
+ * out = LayerNorm(x (+ res)) * gamma + beta over the last dim E; rows of E elements, eps as nn.LayerNorm (1e-5). */
+int ccnet_layernorm(const void* x, const void* res, const float* gamma, const float* beta, void* out, int dtype,
+                    int64_t rows, int E, float eps, ccnet_stream stream);
+/* scaled-dot-product attention over axis S of (S, N, heads*hd) operands (batch_first=False: S is the image batch).
+ * q/k/v are channel slices of [S*N][ld] row buffers: q rows are (s*N + n); Sq queries attend Sk keys.  C = heads*hd. */
+int ccnet_attention(ccnet_slice q, ccnet_slice k, ccnet_slice v, int dtype, int Sq, int Sk, int N, int heads, int hd,
+                    ccnet_slice out, ccnet_stream stream);
+
+/* ---- decode + post-process --------------------------------------------------------------------------------
+ * decode_outputs (utils/bbox.py:13-79).  heads: nlev raw fp32 maps, element (b,c,y,x) of level l at
+ * head_dev[l][b*sb[l] + c*sc[l] + (y*w[l]+x)*sp[l]].  out_dev: fp32 [B][A][5+nc] contiguous.
+ * stride of a level = in_h / h[l] for BOTH axes (bbox.py:57); x,w are divided by in_w and y,h by in_h. */
+int ccnet_decode(const float* const* head_dev, const int64_t* sb, const int64_t* sc, const int64_t* sp, const int32_t* h,
+                 const int32_t* w, int nlev, int B, int nc, float in_h, float in_w, float* out_dev, ccnet_stream stream);
+
+/* post_process part 1 (utils/bbox.py:98-130): cxcywh->xyxy, class max (first index on ties), keep
+ * obj*cls >= conf_thres (fp32 compare), order-preserving compaction.
+ * cand_dev: fp32 [B][A][7] rows [x1,y1,x2,y2,obj,cls_conf,cls_id]; counts_dev: int32 [B]. */
+int ccnet_filter(const float* pred_dev, int B, int A, int nc, float conf_thres, float* cand_dev, int32_t* counts_dev,
+                 ccnet_stream stream);
+/* post_process part 2 (utils/bbox.py:133-158): torchvision.ops.boxes.batched_nms (0.9.0 coordinate trick; third party,
+ * see DESIGN.md) + gather + rescale to image pixels.  nmax >= max(counts).  image_hw_dev: int32 [B][2] = (ih, iw).
+ * det_dev: fp32 [B][nmax][7] rows [top,left,bottom,right,obj,cls_conf,cls_id] in descending score order;
+ * keep_idx_dev: int32 [B][nmax] indices into the image's candidate list; nkeep_dev: int32 [B].
+ * workspace_dev: ccnet_nms_workspace_bytes(B, nmax) bytes. */
+size_t ccnet_nms_workspace_bytes(int B, int nmax);
+int ccnet_nms(const float* cand_dev, const int32_t* counts_dev, int B, int A, int nmax, double nms_thres,
+              const int32_t* image_hw_dev, float* det_dev, int32_t* keep_idx_dev, int32_t* nkeep_dev, void* workspace_dev,
+              ccnet_stream stream);
+
+/* ---- plan: a recorded sequence of the calls above, replayed with one C call per forward --------------------
+ * Replaces the Python-level op-by-op dispatch of Net.forward (network/net.py:194-275 and siblings).
+ * Recording: ccnet_plan_begin(&plan) makes the CALLING THREAD record instead of launch until ccnet_plan_end();
+ * every ccnet_* compute call in between is validated and appended.  A plan is immutable afterwards; one plan is run
+ * by one thread at a time, distinct plans are independent (no global mutable state besides the thread-local recorder). */
+typedef struct ccnet_plan ccnet_plan;
+int ccnet_plan_begin(ccnet_plan** plan);
+int ccnet_plan_end(void);
+int ccnet_plan_num_ops(const ccnet_plan* plan);
+/* x_dev, if not NULL, replaces the image pointer of every recorded ccnet_stem_conv */
+int ccnet_plan_run(const ccnet_plan* plan, const float* x_dev, ccnet_stream stream);
+void ccnet_plan_destroy(ccnet_plan* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCNET_HIP_H */

@@ -1,0 +1,411 @@
+"""Per-kernel parity on the GPU, through the C ABI: every HIP kernel against a plain torch fp32 CPU reference of
+the same op (floating point: tolerance stated per test), NMS/filter against the oracle (bit-exact)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from ccnet_amd import ops
+    return ops
+
+
+def tdt(code):
+    return torch.bfloat16 if code == 1 else torch.float32
+
+
+def to_nhwc(x, code, ldc=None, coff=0):
+    """NCHW cpu fp32 -> NHWC device tensor in a (possibly wider) buffer."""
+    B, Cc, H, W = x.shape
+    ldc = ldc or Cc
+    buf = torch.zeros(B, H, W, ldc, dtype=tdt(code), device=DEV)
+    buf[..., coff:coff + Cc] = x.permute(0, 2, 3, 1).to(DEV).to(tdt(code))
+    return buf
+
+
+def from_nhwc(buf, coff, Cc):
+    return buf[..., coff:coff + Cc].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def q(x, code):
+    """Round through the storage dtype (so the reference sees the same operand values)."""
+    return x.to(tdt(code)).float()
+
+
+def tol(code):
+    # fp32: accumulation-order noise only.  bf16: one rounding of the output (2^-9) plus accumulated operand products.
+    return 2e-5 if code == 0 else 1.2e-2
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, H, W, act, residual
+    (64, 128, 1, 1, 0, 20, 20, "silu", False),
+    (32, 32, 3, 1, 1, 17, 23, "silu", True),
+    (128, 128, 3, 1, 1, 20, 20, "silu", True),
+    (64, 64, 3, 2, 1, 24, 24, "relu", False),
+    (32, 64, 6, 2, 2, 32, 32, "silu", False),
+    (128, 16, 1, 1, 0, 13, 11, "lrelu", False),
+    (256, 512, 1, 1, 0, 7, 7, "relu6", False),
+    (8, 24, 3, 1, 1, 9, 9, "none", False),
+    (128, 5, 1, 1, 0, 20, 20, "none", False),
+]
+
+
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(case, code):
+    ops = _ops()
+    cin, cout, k, stride, pad, H, W, act, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    B = 2
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    pc = ops.PackedConv(w, b, code, DEV)
+    xin = to_nhwc(x, code, ldc=cin + 16, coff=8)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out_dt = 0 if cout == 5 else code
+    ldo = cout + 8 if cout % 8 == 0 else 11
+    out = torch.zeros(B, Ho, Wo, ldo, dtype=tdt(out_dt), device=DEV)
+    res = None
+    ref_res = 0
+    if use_res:
+        r = torch.randn(B, cout, Ho, Wo, generator=g)
+        resbuf = to_nhwc(r, code)
+        res = ops.sl(resbuf)
+        ref_res = q(r, code)
+    ops.conv2d([ops.sl(xin, 8, cin)], pc, B, H, W, stride, pad, ops.sl(out, 0 if cout % 8 else 8, cout), act, res, out_dt)
+    torch.cuda.synchronize()
+    actf = {"silu": F.silu, "relu": F.relu, "relu6": F.relu6, "lrelu": lambda t: F.leaky_relu(t, 0.1), "none": lambda t: t}[act]
+    ref = actf(F.conv2d(q(x, code), q(w, code), b, stride, pad)) + ref_res
+    got = from_nhwc(out, 0 if cout % 8 else 8, cout)
+    assert rel(got, ref) < tol(code), rel(got, ref)
+    # channels outside the slice stay untouched
+    if cout % 8 == 0:
+        assert float(out[..., :8].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("code", [0, 1])
+def test_conv2d_two_segments_with_upsample(code):
+    """torch.cat([nn.Upsample(2)(a), b], 1) -> 1x1 and 3x3 conv without materialising either (network/net.py:208-213)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 12, 16
+    a = torch.randn(B, 32, H // 2, W // 2, generator=g)
+    bb = torch.randn(B, 64, H, W, generator=g)
+    for k in (1, 3):
+        w = torch.randn(48, 96, k, k, generator=g) / math.sqrt(96 * k * k)
+        bias = torch.randn(48, generator=g) * 0.1
+        pc = ops.PackedConv(w, bias, code, DEV)
+        ta, tb = to_nhwc(a, code), to_nhwc(bb, code)
+        out = torch.zeros(B, H, W, 48, dtype=tdt(code), device=DEV)
+        ops.conv2d([ops.sl(ta, 0, 32, shift=1), ops.sl(tb)], pc, B, H, W, 1, k // 2, ops.sl(out), "silu")
+        torch.cuda.synchronize()
+        cat = torch.cat([F.interpolate(q(a, code), scale_factor=2, mode="nearest"), q(bb, code)], 1)
+        ref = F.silu(F.conv2d(cat, q(w, code), bias, 1, k // 2))
+        assert rel(from_nhwc(out, 0, 48), ref) < tol(code)
+
+
+@pytest.mark.parametrize("code", [0, 1])
+def test_s2d_conv_equals_6x6(code):
+    """SpaceToDepth + BaseConv k3 (network/model_block.py:166-175) through the 6x6 stride-2 weight transform."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    B, Cc, H, W = 2, 16, 20, 12
+    x = torch.randn(B, Cc, H, W, generator=g)
+    w3 = torch.randn(40, 4 * Cc, 3, 3, generator=g) / math.sqrt(36 * Cc)
+    pc = ops.PackedConv(ops.s2d_to_6x6(w3), None, code, DEV)
+    out = torch.zeros(B, H // 2, W // 2, 40, dtype=tdt(code), device=DEV)
+    xin = to_nhwc(x, code)
+    ops.conv2d([ops.sl(xin)], pc, B, H, W, 2, 2, ops.sl(out), "none")
+    torch.cuda.synchronize()
+    xq = q(x, code)
+    s2d = torch.cat((xq[..., ::2, ::2], xq[..., ::2, 1::2], xq[..., 1::2, ::2], xq[..., 1::2, 1::2]), 1)
+    ref = F.conv2d(s2d, q(w3, code), None, 1, 1)
+    assert rel(from_nhwc(out, 0, 40), ref) < tol(code)
+
+
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("cout,H,W", [(32, 64, 64), (24, 34, 70), (64, 16, 32)])
+def test_stem_conv(code, cout, H, W):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    B = 2
+    x = torch.randn(B, 3, H, W, generator=g)
+    w6 = torch.randn(cout, 3, 6, 6, generator=g) / math.sqrt(108)
+    b = torch.randn(cout, generator=g) * 0.1
+    wp, bp = ops.pack_stem(w6, b, DEV)
+    out = torch.zeros(B, H // 2, W // 2, cout, dtype=tdt(code), device=DEV)
+    xd = x.to(DEV)
+    ops.stem_conv(xd, wp, bp, cout, "silu", ops.sl(out), code)
+    torch.cuda.synchronize()
+    ref = F.silu(F.conv2d(q(x, code), q(w6, code), b, 2, 2))
+    assert rel(from_nhwc(out, 0, cout), ref) < tol(code)
+
+
+@pytest.mark.parametrize("code", [0, 1])
+def test_dwconv3x3(code):
+    ops = _ops()
+    g = torch.Generator().manual_seed(13)
+    B, Cc, H, W = 2, 64, 7, 9
+    x = torch.randn(B, Cc, H, W, generator=g)
+    w = torch.randn(Cc, 1, 3, 3, generator=g) / 3
+    b = torch.randn(Cc, generator=g) * 0.1
+    out = torch.zeros(B, H, W, Cc, dtype=tdt(code), device=DEV)
+    wt, bd, xin = w.reshape(Cc, 9).t().contiguous().to(DEV), b.to(DEV), to_nhwc(x, code)
+    ops.dwconv3x3(ops.sl(xin), code, B, H, W, wt, bd, ops.sl(out))
+    torch.cuda.synchronize()
+    ref = F.conv2d(q(x, code), w, b, 1, 1, 1, Cc)
+    assert rel(from_nhwc(out, 0, Cc), ref) < (1e-5 if code == 0 else 6e-3)
+
+
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("H,W", [(20, 20), (7, 5), (40, 40)])
+def test_sppf_pool_exact(code, H, W):
+    ops = _ops()
+    g = torch.Generator().manual_seed(17)
+    B, Cc = 2, 32
+    x = q(torch.randn(B, Cc, H, W, generator=g), code)
+    buf = to_nhwc(x, code, ldc=4 * Cc)
+    ops.sppf_pool(ops.sl(buf, 0, Cc), code, B, H, W)
+    torch.cuda.synchronize()
+    y1 = F.max_pool2d(x, 5, 1, 2)
+    y2 = F.max_pool2d(y1, 5, 1, 2)
+    y3 = F.max_pool2d(y2, 5, 1, 2)
+    ref = torch.cat((x, y1, y2, y3), 1)
+    assert torch.equal(from_nhwc(buf, 0, 4 * Cc), ref)  # max is exact in any dtype
+
+
+@pytest.mark.parametrize("code", [0, 1])
+def test_maxpool3x3s2_exact(code):
+    ops = _ops()
+    g = torch.Generator().manual_seed(19)
+    B, Cc, H, W = 2, 16, 11, 14
+    x = q(torch.randn(B, Cc, H, W, generator=g), code)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.zeros(B, Ho, Wo, Cc, dtype=tdt(code), device=DEV)
+    xin = to_nhwc(x, code)
+    ops.maxpool3x3s2(ops.sl(xin), code, B, H, W, ops.sl(out))
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(out, 0, Cc), F.max_pool2d(x, 3, 2, 1))
+
+
+def _cbam_ref(x, fc1, fc2, w7):
+    def mlp(v):
+        return F.conv2d(F.relu(F.conv2d(v, fc1[:, :, None, None])), fc2[:, :, None, None])
+    gate = torch.sigmoid(mlp(F.adaptive_avg_pool2d(x, 1)) + mlp(F.adaptive_max_pool2d(x, 1)))
+    x = x * gate
+    s = torch.cat([x.mean(1, keepdim=True), x.max(1, keepdim=True)[0]], 1)
+    return x * torch.sigmoid(F.conv2d(s, w7[None], None, 1, w7.shape[-1] // 2))
+
+
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("Cc,H,W", [(128, 28, 28), (512, 7, 7), (64, 40, 36), (24, 5, 5)])
+def test_cbam(code, Cc, H, W):
+    ops = _ops()
+    g = torch.Generator().manual_seed(23)
+    B = 2
+    x = torch.randn(B, Cc, H, W, generator=g)
+    cr = max(Cc // 8, 1)
+    fc1 = torch.randn(cr, Cc, generator=g) * 2 / math.sqrt(Cc)
+    fc2 = torch.randn(Cc, cr, generator=g) * 2 / math.sqrt(cr)
+    w7 = torch.randn(2, 7, 7, generator=g) * 0.3
+    scratch = torch.zeros(ops.gate_scratch_floats(B, H, W, Cc), dtype=torch.float32, device=DEV)
+    out = torch.zeros(B, H, W, Cc, dtype=tdt(code), device=DEV)
+    xin, d1, d2, d7 = to_nhwc(x, code), fc1.to(DEV), fc2.to(DEV), w7.to(DEV)
+    ops.cbam(ops.sl(xin), code, B, H, W, d1, d2, d7, scratch, ops.sl(out))
+    torch.cuda.synchronize()
+    ref = _cbam_ref(q(x, code), fc1, fc2, w7)
+    assert rel(from_nhwc(out, 0, Cc), ref) < (2e-5 if code == 0 else 6e-3)
+
+
+@pytest.mark.parametrize("code", [0, 1])
+def test_eca(code):
+    ops = _ops()
+    g = torch.Generator().manual_seed(29)
+    B, Cc, H, W = 2, 128, 14, 14
+    x = torch.randn(B, Cc, H, W, generator=g)
+    w3 = torch.randn(3, generator=g)
+    scratch = torch.zeros(ops.gate_scratch_floats(B, H, W, Cc), dtype=torch.float32, device=DEV)
+    out = torch.zeros(B, H, W, Cc, dtype=tdt(code), device=DEV)
+    xin, d3 = to_nhwc(x, code), w3.to(DEV)
+    ops.eca(ops.sl(xin), code, B, H, W, d3, scratch, ops.sl(out))
+    torch.cuda.synchronize()
+    xq = q(x, code)
+    y = F.adaptive_avg_pool2d(xq, 1)
+    y = F.conv1d(y.squeeze(-1).transpose(-1, -2), w3.view(1, 1, 3), None, 1, 1).transpose(-1, -2).unsqueeze(-1)
+    ref = xq * torch.sigmoid(y)
+    assert rel(from_nhwc(out, 0, Cc), ref) < (2e-5 if code == 0 else 6e-3)
+
+
+@pytest.mark.parametrize("code", [0, 1])
+def test_asff_fuse(code):
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    B, Cc, H, W = 2, 64, 8, 12
+    l0 = torch.randn(B, Cc, H // 4, W // 4, generator=g)
+    l1 = torch.randn(B, Cc, H // 2, W // 2, generator=g)
+    l2 = torch.randn(B, Cc, H, W, generator=g)
+    lg = torch.randn(B, 3, H, W, generator=g) * 2
+    out = torch.zeros(B, H, W, Cc, dtype=tdt(code), device=DEV)
+    lgb = to_nhwc(lg, code, ldc=8)
+    t0, t1, t2 = to_nhwc(l0, code), to_nhwc(l1, code), to_nhwc(l2, code)
+    ops.asff_fuse(ops.sl(t0, shift=2), ops.sl(t1, shift=1), ops.sl(t2), ops.sl(lgb, 0, 3), code, B, H, W, ops.sl(out))
+    torch.cuda.synchronize()
+    wgt = torch.softmax(q(lg, code), 1)
+    ref = (F.interpolate(q(l0, code), scale_factor=4, mode="nearest") * wgt[:, 0:1]
+           + F.interpolate(q(l1, code), scale_factor=2, mode="nearest") * wgt[:, 1:2] + q(l2, code) * wgt[:, 2:3])
+    assert rel(from_nhwc(out, 0, Cc), ref) < (2e-5 if code == 0 else 6e-3)
+
+
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("E,rows", [(256, 100), (96, 7), (640, 33)])
+def test_layernorm_residual(code, E, rows):
+    ops = _ops()
+    g = torch.Generator().manual_seed(37)
+    x, r = torch.randn(rows, E, generator=g), torch.randn(rows, E, generator=g)
+    gam, bet = torch.rand(E, generator=g) + 0.5, torch.randn(E, generator=g) * 0.1
+    xd, rd = x.to(DEV).to(tdt(code)), r.to(DEV).to(tdt(code))
+    out = torch.zeros(rows, E, dtype=tdt(code), device=DEV)
+    gd, bd = gam.to(DEV), bet.to(DEV)
+    ops.layernorm(xd, rd, gd, bd, out, code, rows, E)
+    out2 = torch.zeros(rows, E, dtype=tdt(code), device=DEV)
+    ops.layernorm(xd, None, gd, bd, out2, code, rows, E)
+    torch.cuda.synchronize()
+    ref = F.layer_norm(q(x, code) + q(r, code), (E,), gam, bet, 1e-5)
+    ref2 = F.layer_norm(q(x, code), (E,), gam, bet, 1e-5)
+    t = 2e-5 if code == 0 else 6e-3
+    assert rel(out.float().cpu(), ref) < t and rel(out2.float().cpu(), ref2) < t
+
+
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("Sq,Sk,N,heads,hd", [(1, 1, 49, 2, 128), (4, 4, 10, 2, 128), (5, 70, 3, 2, 96), (64, 64, 6, 2, 128)])
+def test_attention_over_batch_axis(code, Sq, Sk, N, heads, hd):
+    """MultiheadAttention core with batch_first=False operands (S, N, E) (network/model_block.py:288-290)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(41)
+    E = heads * hd
+    qkv_q = torch.randn(Sq, N, 3 * E, generator=g)
+    kv = torch.randn(Sk, N, 3 * E, generator=g) if Sk != Sq else qkv_q
+    qd, kd = qkv_q.to(DEV).to(tdt(code)), kv.to(DEV).to(tdt(code))
+    out = torch.zeros(Sq, N, E, dtype=tdt(code), device=DEV)
+    ops.attention(ops.sl(qd, 0, E), ops.sl(kd, E, E), ops.sl(kd, 2 * E, E), code, Sq, Sk, N, heads, hd, ops.sl(out))
+    torch.cuda.synchronize()
+    qq, kk, vv = q(qkv_q[..., :E], code), q(kv[..., E:2 * E], code), q(kv[..., 2 * E:], code)
+    qh = qq.reshape(Sq, N * heads, hd).transpose(0, 1)
+    kh = kk.reshape(Sk, N * heads, hd).transpose(0, 1)
+    vh = vv.reshape(Sk, N * heads, hd).transpose(0, 1)
+    att = torch.softmax(torch.bmm(qh, kh.transpose(1, 2)) / math.sqrt(hd), -1)
+    ref = torch.bmm(att, vh).transpose(0, 1).reshape(Sq, N, E)
+    assert rel(out.float().cpu(), ref) < (2e-5 if code == 0 else 6e-3)
+
+
+def test_decode_matches_oracle_layouts():
+    from oracle import ccnet_oracle as orc
+    ops = _ops()
+    g = torch.Generator().manual_seed(43)
+    B, nc = 3, 6
+    hw = [(20, 32), (10, 16), (5, 8)]
+    heads = [torch.randn(B, 5 + nc, h, w, generator=g) * 2 for h, w in hw]
+    A = sum(h * w for h, w in hw)
+    ref = orc.decode_outputs(heads, [160, 256])
+    # (a) NCHW contiguous, (b) NHWC buffers permuted to NCHW views (what Net.forward returns)
+    for mode in ("nchw", "nhwc"):
+        dev = []
+        for h in heads:
+            d = h.to(DEV)
+            if mode == "nhwc":
+                d = d.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+            dev.append(d)
+        out = torch.zeros(B, A, 5 + nc, dtype=torch.float32, device=DEV)
+        ops.decode(dev, nc, 160, 256, out)
+        torch.cuda.synchronize()
+        # fp32 tolerance: expf/sigmoid differ from ATen's vectorised CPU versions by a few ulp
+        assert torch.allclose(out.cpu(), ref, rtol=2e-6, atol=1e-7), float((out.cpu() - ref).abs().max())
+
+
+def _run_post(pred, nc, conf, thr, info):
+    from ccnet_amd.utils import bbox
+    return bbox.post_process(pred.clone(), nc, [160, 256], info, conf, thr)
+
+
+@pytest.mark.parametrize("conf,thr", [(0.5, 0.6), (0.001, 0.6), (0.3, 0.4), (0.99999, 0.5)])
+def test_post_process_bit_exact_vs_oracle(conf, thr):
+    from oracle import ccnet_oracle as orc
+    g = torch.Generator().manual_seed(47)
+    B, A, nc = 3, 1500, 6
+    pred = torch.rand(B, A, 5 + nc, generator=g)
+    pred[..., 2:4] = pred[..., 2:4] * 0.2 + 0.01
+    pred[1, :, 4] *= 0.3
+    info = [[i, 300 + 7 * i, 200 + 3 * i] for i in range(B)]
+    ref = orc.post_process(pred, nc, [160, 256], info, conf, thr)
+    got = _run_post(pred.to(DEV), nc, conf, thr, info)
+    assert len(got) == len(ref)
+    for a, b in zip(got, ref):
+        assert a.dtype == np.float32 and a.shape == b.shape
+        assert np.array_equal(a, b)
+
+
+def test_nms_known_answers():
+    """Hand-checkable cases: identical boxes, touching boxes (IoU 0), IoU exactly at the threshold (kept: '>' not '>='),
+    cross-class overlap kept, score ties (lower index wins), zero-area boxes (NaN IoU never suppresses), empty input."""
+    from oracle import ccnet_oracle as orc
+    from ccnet_amd.utils import bbox
+
+    def run(boxes, scores, cls, thr):
+        n = len(boxes)
+        cand = torch.zeros(1, max(n, 1), 7)
+        for i in range(n):
+            cand[0, i, :4] = torch.tensor(boxes[i])
+            cand[0, i, 4], cand[0, i, 5], cand[0, i, 6] = scores[i], 1.0, cls[i]
+        keep = bbox.nms_keep_indices(cand.to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV), thr)[0]
+        b = np.asarray(boxes, np.float32).reshape(-1, 4)
+        ref = orc.batched_nms_reference(b, np.asarray(scores, np.float32), np.asarray(cls, np.float32), thr)
+        assert list(keep) == list(ref), (keep, ref)
+        return list(keep)
+
+    assert run([[0, 0, 1, 1], [0, 0, 1, 1]], [0.9, 0.8], [0, 0], 0.5) == [0]
+    assert run([[0, 0, 1, 1], [1, 0, 2, 1]], [0.9, 0.8], [0, 0], 0.5) == [0, 1]
+    # IoU = 0.5 exactly: [0,0,2,1] vs [0,0,1,1] -> inter 1, union 2
+    assert run([[0, 0, 2, 1], [0, 0, 1, 1]], [0.9, 0.8], [0, 0], 0.5) == [0, 1]
+    assert run([[0, 0, 2, 1], [0, 0, 1, 1]], [0.9, 0.8], [0, 0], 0.49) == [0]
+    assert run([[0, 0, 1, 1], [0, 0, 1, 1]], [0.9, 0.8], [0, 1], 0.5) == [0, 1]
+    assert run([[0, 0, 1, 1], [0, 0, 1, 1], [0, 0, 1, 1]], [0.7, 0.7, 0.7], [0, 0, 0], 0.5) == [0]
+    assert run([[0.5, 0.5, 0.5, 0.5], [0.5, 0.5, 0.5, 0.5]], [0.9, 0.8], [0, 0], 0.5) == [0, 1]
+    assert run([], [], [], 0.5) == []
+
+
+def test_nms_heavy_bit_exact():
+    """SURVEY 8(d) NMS microbench shape at reduced size: log-normal boxes, 6 classes, uniform scores."""
+    from oracle import ccnet_oracle as orc
+    from ccnet_amd.utils import bbox
+    rng = np.random.RandomState(0)
+    B, n = 2, 3000
+    cand = np.zeros((B, n + 50, 7), np.float32)
+    counts = []
+    for b in range(B):
+        nb = n - 137 * b
+        c = rng.uniform(0, 1, (nb, 2))
+        wh = np.exp(rng.normal(math.log(0.05), 0.5, (nb, 2)))
+        cand[b, :nb, 0:2] = c - wh / 2
+        cand[b, :nb, 2:4] = c + wh / 2
+        cand[b, :nb, 4] = rng.uniform(0, 1, nb)
+        cand[b, :nb, 5] = rng.uniform(0.5, 1, nb)
+        cand[b, :nb, 6] = rng.randint(0, 6, nb)
+        counts.append(nb)
+    keep = bbox.nms_keep_indices(torch.from_numpy(cand).to(DEV), torch.tensor(counts, dtype=torch.int32, device=DEV), 0.6)
+    for b in range(B):
+        nb = counts[b]
+        ref = orc.batched_nms_reference(cand[b, :nb, :4], cand[b, :nb, 4] * cand[b, :nb, 5], cand[b, :nb, 6], 0.6)
+        assert np.array_equal(np.asarray(keep[b], np.int64), ref)
