@@ -1,0 +1,79 @@
+"""nn.Module front of the MI355X path: same constructor, state_dict and forward contract as the reference's Net
+classes (network/net.py:16-23,194-275), with forward executed as one recorded libccnet_hip plan."""
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from . import graph
+
+
+class NetBase(nn.Module):
+    KIND = None
+
+    def __init__(self, depth=1.0, width=1.0, num_classes=80, act="silu"):
+        super().__init__()
+        if act not in ("silu", "relu", "relu6", "lrelu"):
+            # same failure as get_activation_function (network/model_block.py:32-33)
+            raise AttributeError("Unsupported activation function type: {}".format(act))
+        self._cfg = graph.declare(self, self.KIND, depth, width, num_classes)
+        self._act = act
+        self._plans = {}
+        self._version = 0
+        self.precision = os.environ.get("CCNET_PRECISION", "bf16")
+        self.alias_outputs = False  # True: return views of the plan's own head buffers (overwritten by the next call)
+        self.eval()
+
+    # ---- weights changed -> recorded plans hold stale packed copies
+    def _invalidate(self):
+        self._plans = {}
+        self._version += 1
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._invalidate()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._invalidate()
+        return r
+
+    def set_precision(self, precision):
+        """"bf16": bf16 storage / fp32 accumulate (head logits and decode stay fp32); "fp32": exact-fp32 MFMA everywhere."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.precision = precision
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise RuntimeError("ccnet_amd Net is inference-only (BN is folded with its running statistics); use the reference to train")
+        return super().train(False)
+
+    def plan_for(self, B, H, W, device):
+        dtype = _lib.BF16 if self.precision == "bf16" else _lib.F32
+        key = (B, H, W, dtype, str(device))
+        ent = self._plans.get(key)
+        if ent is None:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            with torch.cuda.device(device):
+                ent = graph.compile_plan(self.KIND, sd, self._cfg, B, H, W, dtype, device, self._act)
+            self._plans[key] = ent
+        return ent
+
+    def forward(self, x):
+        """x: float32 CUDA (B,3,H,W), H and W multiples of 32.  Returns the list of raw head maps (B, 5+nc, H/s, W/s),
+        fp32, channel order [reg4, obj1, cls nc] -- same values/shapes as the reference; memory is NHWC underneath."""
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("Net.forward expects a (B,3,H,W) tensor")
+        if not x.is_cuda:
+            raise RuntimeError("ccnet_amd Net runs on the GPU only (libccnet_hip has no CPU path); move the input to 'cuda'")
+        x = x.float().contiguous()
+        B, _, H, W = x.shape
+        plan, heads, _ = self.plan_for(B, H, W, x.device)
+        with torch.cuda.device(x.device):
+            plan.run(x)
+        outs = [h.permute(0, 3, 1, 2) for h in heads]
+        return outs if self.alias_outputs else [o.clone(memory_format=torch.preserve_format) for o in outs]
