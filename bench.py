@@ -1,0 +1,182 @@
+"""Headline benchmark: images/s of forward + decode_outputs + post_process (NMS), CCNet `network.net.Net`
+(s size, 6 classes) at 640x640, 64 images per GPU, bf16 storage / fp32 accumulate, synthetic images and weights.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...     (one rank per GPU, weak scaling)
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events around every conv launch of one extra
+forward (on the stream the kernels run on); `cpu_baseline` times the CPU oracle (a port of the reference path) on a
+bounded sample on rank 0 when N == 1.  Nothing here reads /root/reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_MFMA_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+OP_CONV = 1
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--kind", default="net")
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--conf", type=float, default=0.5)
+    ap.add_argument("--nms", type=float, default=0.6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-op-kind time table to stderr")
+    return ap.parse_args()
+
+
+def build_model(kind, precision):
+    import importlib
+    from ccnet_amd import synth
+    net = importlib.import_module("ccnet_amd.network." + kind).Net(0.33, 0.5, 6, "silu")
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=0, bn_calib=kind))
+    return net
+
+
+def cpu_baseline(kind, size, conf, nms):
+    """Oracle (CPU port of the reference path) on a bounded sample: 1 warm-up + 2 timed passes of 4 images."""
+    from ccnet_amd import synth
+    from oracle import ccnet_oracle as orc
+    import importlib
+    net = importlib.import_module("ccnet_amd.network." + kind).Net(0.33, 0.5, 6, "silu")
+    sd = synth.synth_state_dict(net.state_dict(), seed=0, bn_calib=kind)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    bs = 4
+    x = synth.synth_images(bs, size, size, seed=0)
+    info = [[i, size, size] for i in range(bs)]
+
+    def once():
+        heads = orc.forward(kind, sd, x, 0.33, 0.5, "silu")
+        dec = orc.decode_outputs(heads, [size, size])
+        return orc.post_process(dec, 6, [size, size], info, conf, nms)
+
+    once()
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        once()
+    dt = time.perf_counter() - t0
+    return {"value": round(bs * reps / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "%s %dx%d bs%d fp32 fwd+decode+NMS, %d passes after 1 warm-up (torch CPU oracle)" % (kind, size, size, bs, reps)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from ccnet_amd import synth
+    from ccnet_amd.parallel import all_gather_detections
+    from ccnet_amd.utils import bbox
+
+    B, S = args.batch, args.size
+    net = build_model(args.kind, args.precision).to(dev).set_precision(args.precision)
+    net.alias_outputs = True
+    # every rank owns its own slice of the global synthetic batch (image i depends only on its global index)
+    x = torch.stack([synth.synth_images(1, S, S, seed=1000 + rank * B + i)[0] for i in range(min(B, 8))], 0)
+    x = x.repeat((B + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
+    info = [[i, S, S] for i in range(B)]
+
+    def step():
+        outs = net(x)
+        dec = bbox.decode_outputs(outs, [S, S])
+        dets = bbox.post_process(dec, 6, [S, S], info, args.conf, args.nms)
+        if world > 1:
+            dets = all_gather_detections(dets, device=dev)
+        return dets
+
+    for _ in range(args.warmup):
+        dets = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dets = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    # ---- roofline of the dominant kernel family (conv_igemm): HIP events around every op of one forward
+    plan, _, _ = net.plan_for(B, S, S, dev)
+    plan.run_timed(x)
+    ms = None
+    for _ in range(3):
+        cur = plan.run_timed(x)
+        ms = cur if ms is None else [min(a, b) for a, b in zip(ms, cur)]
+    infos = plan.op_info()
+    conv_ms = sum(m for m, (k, f, b) in zip(ms, infos) if k == OP_CONV)
+    conv_fl = sum(f for (k, f, b) in infos if k == OP_CONV)
+    n_conv = sum(1 for (k, f, b) in infos if k == OP_CONV)
+    peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else FP32_MFMA_PEAK_TFLOPS
+    achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": None, "kernel": "conv_igemm_kernel (all %d conv/linear launches of one forward)" % n_conv,
+                "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2), "flops_per_forward": conv_fl,
+                "forward_ms_sum_of_ops": round(sum(ms), 3)}
+    if args.breakdown and rank == 0:
+        names = {0: "other", 1: "conv", 2: "stem", 3: "dwconv", 4: "sppf", 5: "maxpool", 6: "cbam", 7: "eca", 8: "asff", 9: "layernorm",
+                 10: "attention"}
+        agg = {}
+        for m, (k, f, b) in zip(ms, infos):
+            a = agg.setdefault(k, [0.0, 0.0, 0.0, 0])
+            a[0] += m; a[1] += f; a[2] += b; a[3] += 1
+        for k, (m, f, b, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+            print("%-10s n=%3d  %8.3f ms  %8.1f TFLOP/s  %8.1f GB/s(alg)" % (names.get(k, k), n, m, f / (m * 1e-3) / 1e12 if m else 0,
+                                                                             b / (m * 1e-3) / 1e9 if m else 0), file=sys.stderr)
+        top = sorted(zip(ms, infos, range(len(ms))), key=lambda t: -t[0])[:25]
+        for m, (k, f, b), i in top:
+            print("  op %3d %-9s %7.3f ms %7.1f TF/s %7.1f GB/s" % (i, names.get(k, k), m, f / (m * 1e-3) / 1e12, b / (m * 1e-3) / 1e9), file=sys.stderr)
+
+    out = {"metric": "images/sec (fwd+decode+NMS) 640x640 bs64 per GPU", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+           "config": {"workload": "CCNet %s (s: depth 0.33, width 0.5, 6 classes) %dx%d, %d images/GPU, fwd+decode+post_process "
+                                  "(conf %.3g, nms %.3g)%s" % (args.kind, S, S, B, args.conf, args.nms,
+                                                                ", all_gather of detections" if world > 1 else ""),
+                      "global_batch": world * B, "parallelism": "batch-sharded replicas x%d" % world,
+                      "detections_last_step": int(sum(0 if d is None else d.shape[0] for d in dets))},
+           "roofline": roofline}
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.kind, S, args.conf, args.nms)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

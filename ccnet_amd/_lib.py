@@ -62,6 +62,8 @@ def lib():
         L.ccnet_plan_num_ops.argtypes = [vp]
         L.ccnet_plan_run.argtypes = [vp, vp, vp]
         L.ccnet_plan_destroy.argtypes = [vp]
+        L.ccnet_plan_op_info.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(f64), C.POINTER(f64)]
+        L.ccnet_plan_run_timed.argtypes = [vp, vp, vp, C.POINTER(f32)]
         L.ccnet_plan_destroy.restype = None
         _lib = L
     return _lib

@@ -28,8 +28,9 @@ int ccnet_set_error(int code, const char* fmt, ...);
 
 // A recorded or immediate launch.  x_override replaces the stem image pointer when not null.
 using ccnet_launch_fn = std::function<int(hipStream_t, const float* x_override)>;
-// Runs `fn` now on `stream`, or appends it to the calling thread's open plan.
-int ccnet_submit(ccnet_launch_fn fn, ccnet_stream stream);
+// Runs `fn` now on `stream`, or appends it to the calling thread's open plan.  kind/flops/bytes describe the op for
+// ccnet_plan_op_info (algorithmic work: 2*MAC flops; each distinct input and output element counted once).
+int ccnet_submit(ccnet_launch_fn fn, ccnet_stream stream, int kind = 0, double flops = 0.0, double bytes = 0.0);
 
 static inline bool cc_dtype_ok(int d) { return d == CCNET_F32 || d == CCNET_BF16; }
 static inline int cc_esize(int d) { return d == CCNET_BF16 ? 2 : 4; }

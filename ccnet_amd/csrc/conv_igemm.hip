@@ -309,5 +309,7 @@ extern "C" int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream) {
             if (dt == CCNET_BF16) return odt == CCNET_BF16 ? launch<__bf16, __bf16>(p, bn, st) : launch<__bf16, float>(p, bn, st);
             return launch<float, float>(p, bn, st);
         },
-        stream);
+        stream, CCNET_OP_CONV, 2.0 * (double)p.M * d->Cout * d->kh * d->kw * ctot,
+        ((double)d->B * d->H * d->W * ctot + (double)d->Cout * d->kh * d->kw * ctot) * cc_esize(d->dtype) +
+            (double)p.M * d->Cout * (cc_esize(d->out_dtype) + (d->residual.ptr ? cc_esize(d->dtype) : 0)));
 }

@@ -289,7 +289,7 @@ extern "C" int ccnet_decode(const float* const* head_dev, const int64_t* sb, con
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
-        stream);
+        stream, CCNET_OP_DECODE, 0.0, 2.0 * B * (double)A * (5 + nc) * 4.0);
 }
 
 extern "C" int ccnet_filter(const float* pred_dev, int B, int A, int nc, float conf_thres, float* cand_dev, int32_t* counts_dev,
@@ -302,7 +302,7 @@ extern "C" int ccnet_filter(const float* pred_dev, int B, int A, int nc, float c
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
-        stream);
+        stream, CCNET_OP_FILTER, 0.0, (double)B * A * (5 + nc) * 4.0);
 }
 
 extern "C" size_t ccnet_nms_workspace_bytes(int B, int nmax) {
@@ -337,5 +337,5 @@ extern "C" int ccnet_nms(const float* cand_dev, const int32_t* counts_dev, int B
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
-        stream);
+        stream, CCNET_OP_NMS, 0.0, 0.0);
 }

@@ -300,7 +300,7 @@ extern "C" int ccnet_cbam(ccnet_slice in, int dtype, int B, int H, int W, const 
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
-        stream);
+        stream, CCNET_OP_CBAM, 0.0, 2.0 * B * H * W * (double)C * cc_esize(dtype));
 }
 
 extern "C" int ccnet_eca(ccnet_slice in, int dtype, int B, int H, int W, const float* w3, float* scratch_dev, ccnet_slice out,
@@ -331,7 +331,7 @@ extern "C" int ccnet_eca(ccnet_slice in, int dtype, int B, int H, int W, const f
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
-        stream);
+        stream, CCNET_OP_ECA, 0.0, 2.0 * B * H * W * (double)C * cc_esize(dtype));
 }
 
 extern "C" int ccnet_asff_fuse(ccnet_slice l0, ccnet_slice l1, ccnet_slice l2, ccnet_slice logits, int dtype, int B, int H, int W, ccnet_slice out,
@@ -359,5 +359,7 @@ extern "C" int ccnet_asff_fuse(ccnet_slice l0, ccnet_slice l1, ccnet_slice l2, c
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
-        stream);
+        stream, CCNET_OP_ASFF, 0.0,
+        ((double)B * H * W * out.C + (double)B * (H >> l0.shift) * (W >> l0.shift) * out.C + (double)B * (H >> l1.shift) * (W >> l1.shift) * out.C +
+         (double)B * (H >> l2.shift) * (W >> l2.shift) * out.C) * cc_esize(dtype));
 }

@@ -113,7 +113,7 @@ extern "C" int ccnet_sppf_pool(ccnet_slice buf, int dtype, int B, int H, int W, 
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
-        stream);
+        stream, CCNET_OP_SPPF, 0.0, 4.0 * B * H * W * (double)buf.C * cc_esize(dtype));
 }
 
 extern "C" int ccnet_maxpool3x3s2(ccnet_slice in, int dtype, int B, int H, int W, ccnet_slice out, ccnet_stream stream) {
@@ -134,5 +134,5 @@ extern "C" int ccnet_maxpool3x3s2(ccnet_slice in, int dtype, int B, int H, int W
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
-        stream);
+        stream, CCNET_OP_MAXPOOL, 0.0, ((double)B * H * W + (double)B * Ho * Wo) * in.C * cc_esize(dtype));
 }

@@ -161,7 +161,8 @@ int launch_stem(const StemP& p, const float* x, hipStream_t st) {
         case 1: hipLaunchKernelGGL((stem_kernel<T, OutT, 1>), grid, dim3(256), 0, st, p, x); break;
         case 2: hipLaunchKernelGGL((stem_kernel<T, OutT, 2>), grid, dim3(256), 0, st, p, x); break;
         case 3: hipLaunchKernelGGL((stem_kernel<T, OutT, 3>), grid, dim3(256), 0, st, p, x); break;
-        default: hipLaunchKernelGGL((stem_kernel<T, OutT, 4>), grid, dim3(256), 0, st, p, x); break;
+        case 4: hipLaunchKernelGGL((stem_kernel<T, OutT, 4>), grid, dim3(256), 0, st, p, x); break;
+        default: hipLaunchKernelGGL((stem_kernel<T, OutT, 5>), grid, dim3(256), 0, st, p, x); break;
     }
     CC_LAUNCH_CHECK();
     return CCNET_OK;
@@ -174,7 +175,7 @@ extern "C" int ccnet_stem_conv(const float* x_dev, int B, int H, int W, const fl
     CC_REQUIRE(x_dev && weight && bias, "stem_conv: null pointer");
     CC_REQUIRE(B > 0 && H >= 2 && W >= 2 && (H % 2) == 0 && (W % 2) == 0, "stem_conv: H,W must be even (got %d,%d)", H, W);
     CC_REQUIRE(B <= 65535, "stem_conv: batch too large for one launch");
-    CC_REQUIRE(Cout > 0 && Cout <= 64 && (Cout % 8) == 0, "stem_conv: Cout must be a multiple of 8, at most 64 (got %d)", Cout);
+    CC_REQUIRE(Cout > 0 && Cout <= 80 && (Cout % 8) == 0, "stem_conv: Cout must be a multiple of 8, at most 80 (got %d)", Cout);
     CC_REQUIRE(cc_dtype_ok(out_dtype) && cc_slice_vec_ok(out, out_dtype) && (out.ldc % 8) == 0 && (out.coff % 8) == 0 && out.C == Cout &&
                    out.shift == 0, "stem_conv: bad output slice");
     CC_REQUIRE(act >= CCNET_ACT_NONE && act <= CCNET_ACT_LRELU, "stem_conv: unknown activation");
@@ -184,7 +185,8 @@ extern "C" int ccnet_stem_conv(const float* x_dev, int B, int H, int W, const fl
             const float* x = xo ? xo : p.x;
             return out_dtype == CCNET_BF16 ? launch_stem<__bf16, __bf16>(p, x, st) : launch_stem<float, float>(p, x, st);
         },
-        stream);
+        stream, CCNET_OP_STEM, 2.0 * B * (H / 2) * (W / 2) * (double)Cout * 108.0,
+        (double)B * 3 * H * W * 4 + (double)B * (H / 2) * (W / 2) * Cout * cc_esize(out_dtype));
 }
 
 extern "C" int ccnet_dwconv3x3(ccnet_slice in, int dtype, int B, int H, int W, const float* weight, const float* bias, ccnet_slice out,
@@ -206,5 +208,5 @@ extern "C" int ccnet_dwconv3x3(ccnet_slice in, int dtype, int B, int H, int W, c
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
-        stream);
+        stream, CCNET_OP_DWCONV, 2.0 * B * H * W * (double)in.C * 9.0, 2.0 * B * H * W * (double)in.C * cc_esize(dtype));
 }

@@ -172,7 +172,7 @@ extern "C" int ccnet_layernorm(const void* x, const void* res, const float* gamm
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
-        stream);
+        stream, CCNET_OP_LAYERNORM, 0.0, (double)rows * E * cc_esize(dtype) * (res ? 3.0 : 2.0));
 }
 
 extern "C" int ccnet_attention(ccnet_slice q, ccnet_slice k, ccnet_slice v, int dtype, int Sq, int Sk, int N, int heads, int hd, ccnet_slice out,
@@ -199,5 +199,6 @@ extern "C" int ccnet_attention(ccnet_slice q, ccnet_slice k, ccnet_slice v, int 
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
-        stream);
+        stream, CCNET_OP_ATTENTION, 4.0 * (double)Sq * Sk * N * heads * hd,
+        ((double)Sq * 2 + (double)Sk * 2) * N * (double)C * cc_esize(dtype));
 }

@@ -201,6 +201,22 @@ class Plan:
     def run(self, x=None):
         check(lib().ccnet_plan_run(self.handle, None if x is None else x.data_ptr(), stream_ptr()))
 
+    def op_info(self):
+        """[(kind, flops, bytes)] per recorded op (include/ccnet_hip.h CCNET_OP_*)."""
+        out = []
+        k, f, b = C.c_int32(), C.c_double(), C.c_double()
+        for i in range(self.num_ops):
+            check(lib().ccnet_plan_op_info(self.handle, i, C.byref(k), C.byref(f), C.byref(b)))
+            out.append((k.value, f.value, b.value))
+        return out
+
+    def run_timed(self, x=None):
+        """Run with a HIP event pair around every op on the current stream; returns ms per op (synchronises)."""
+        n = self.num_ops
+        ms = (C.c_float * n)()
+        check(lib().ccnet_plan_run_timed(self.handle, None if x is None else x.data_ptr(), stream_ptr(), ms))
+        return list(ms)
+
     def __del__(self):
         try:
             if self.handle:

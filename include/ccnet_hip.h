@@ -83,7 +83,7 @@ int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream);
 /* ---- network stem: 6x6 stride-2 pad-2 conv on the NCHW fp32 image, folded BN, activation ------------------
  * Replaces FocusReplaceConv (network/net_deploy.py:41) and SpaceToDepth(3,..)+BaseConv k3 (network/net.py:40)
  * in its 6x6 form.  x_dev: fp32 [B][3][H][W] (the tensor the reference's callers build, tools/demo.py:56-65).
- * weight: fp32 [Cout][160] with k = (c*6 + ky)*8 + kx (kx 6,7 and rows 18,19 zero).  Cout must be <= 64 and % 16 == 0. */
+ * weight: fp32 [Cout][160] with k = (c*6 + ky)*8 + kx (kx 6,7 and rows 18,19 zero).  Cout must be <= 80 and % 8 == 0. */
 int ccnet_stem_conv(const float* x_dev, int B, int H, int W, const float* weight, const float* bias, int Cout,
                     int act, ccnet_slice out, int out_dtype, ccnet_stream stream);
 
@@ -156,6 +156,15 @@ int ccnet_plan_num_ops(const ccnet_plan* plan);
 /* x_dev, if not NULL, replaces the image pointer of every recorded ccnet_stem_conv */
 int ccnet_plan_run(const ccnet_plan* plan, const float* x_dev, ccnet_stream stream);
 void ccnet_plan_destroy(ccnet_plan* plan);
+/* Measurement aids (bench.py): what op i is and its algorithmic work (flops = 2*MAC; bytes = every distinct input and
+ * output element once), and a run that brackets every op with HIP events ON `stream` and synchronises it. */
+enum {
+    CCNET_OP_OTHER = 0, CCNET_OP_CONV = 1, CCNET_OP_STEM = 2, CCNET_OP_DWCONV = 3, CCNET_OP_SPPF = 4, CCNET_OP_MAXPOOL = 5,
+    CCNET_OP_CBAM = 6, CCNET_OP_ECA = 7, CCNET_OP_ASFF = 8, CCNET_OP_LAYERNORM = 9, CCNET_OP_ATTENTION = 10,
+    CCNET_OP_DECODE = 11, CCNET_OP_FILTER = 12, CCNET_OP_NMS = 13
+};
+int ccnet_plan_op_info(const ccnet_plan* plan, int i, int* kind, double* flops, double* bytes);
+int ccnet_plan_run_timed(const ccnet_plan* plan, const float* x_dev, ccnet_stream stream, float* ms_per_op);
 
 #ifdef __cplusplus
 }
