@@ -40,19 +40,23 @@ struct ConvP {
     int vec_out;  // 1: channel groups of 8 are aligned in out/residual
 };
 
+// native vector type for everything staged through registers (HIP's uint4 is a struct wrapping a union, which LLVM
+// sometimes leaves in scratch when held in small arrays)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 template <typename T> struct Frag;
 template <> struct Frag<__bf16> {
-    static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x4& acc) {
+    static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& acc) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     }
 };
 template <> struct Frag<float> {
-    static __device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x4& acc) {
-        float4 fa = __builtin_bit_cast(float4, a), fb = __builtin_bit_cast(float4, b);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.x, fb.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.y, fb.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.z, fb.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.w, fb.w, acc, 0, 0, 0);
+    static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& acc) {
+        f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], acc, 0, 0, 0);
     }
 };
 
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvP p) {
             iy0[i] = oy * p.stride - p.pad;
             ix0[i] = ox * p.stride - p.pad;
         } else {
-            bb[i] = -1; iy0[i] = 0; ix0[i] = 0;
+            bb[i] = 0; iy0[i] = -(1 << 28); ix0[i] = 0;  // row past M: every tap is out of the image
         }
     }
     // K cursor of this thread's chunk: channel c within the concatenated input, tap (ky, kx)
@@ -103,27 +107,33 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvP p) {
     const bool b_active = (BN >= 32) || (t < BN * 8);
     const unsigned char* wrow = p.weight + ((size_t)(n0 + lr) * p.Kpad + lc * EPC) * ES;
 
-    uint4 ra[A_LOADS], rb[B_LOADS];
+    u32x4 ra[A_LOADS], rb[B_LOADS];
+    unsigned okbits = 0u;
     auto gather = [&](int kstep) {
         const int s = (c >= p.C0) ? 1 : 0;
         const SegP& sg = p.seg[s];
         const int cs = c - (s ? p.C0 : 0);
         const bool tap_ok = ky < p.kh;
+        const unsigned char* sbase = sg.ptr + (size_t)(sg.coff + cs) * ES;
+        okbits = 0u;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            int iy = iy0[i] + ky, ix = ix0[i] + kx;
-            bool ok = tap_ok && bb[i] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                size_t pix = ((size_t)bb[i] * sg.Hs + (iy >> sg.shift)) * sg.Ws + (ix >> sg.shift);
-                v = *(const uint4*)(sg.ptr + (pix * sg.ldc + sg.coff + cs) * ES);
-            }
-            ra[i] = v;
+            const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+            const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            // branch-free: out-of-image taps load a clamped (always mapped) pixel and are zeroed when the tile is
+            // written to LDS, so the loads of a K step issue back to back and stay in flight across the MFMAs
+            const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+            const size_t pix = ((size_t)bb[i] * sg.Hs + (iyc >> sg.shift)) * sg.Ws + (ixc >> sg.shift);
+            ra[i] = *(const u32x4*)(sbase + pix * sg.ldc * ES);
+            okbits |= (ok ? 1u : 0u) << i;
         }
-        if (b_active) {
+        if constexpr (BN >= 32) {
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i)
-                rb[i] = *(const uint4*)(wrow + ((size_t)(32 * i) * p.Kpad + (size_t)kstep * BK) * ES);
+                rb[i] = *(const u32x4*)(wrow + ((size_t)(32 * i) * p.Kpad + (size_t)kstep * BK) * ES);
+        } else {
+            // BN == 16: only 128 threads own a weight chunk; the others re-read row 0's chunk and never store it
+            rb[0] = *(const u32x4*)((b_active ? wrow : wrow - (size_t)lr * p.Kpad * ES) + (size_t)kstep * BK * ES);
         }
     };
     auto advance = [&]() {
@@ -137,10 +147,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvP p) {
         unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
         unsigned char* Bs = As + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) *(uint4*)(As + lds_off(lr + 32 * i, lc)) = ra[i];
+        for (int i = 0; i < A_LOADS; ++i)
+            *(u32x4*)(As + lds_off(lr + 32 * i, lc)) = ((okbits >> i) & 1u) ? ra[i] : u32x4{0u, 0u, 0u, 0u};
         if (b_active) {
 #pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) *(uint4*)(Bs + lds_off(lr + 32 * i, lc)) = rb[i];
+            for (int i = 0; i < B_LOADS; ++i) *(u32x4*)(Bs + lds_off(lr + 32 * i, lc)) = rb[i];
         }
     };
 
@@ -150,33 +161,36 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    gather(0);
-    stage(0);
-    __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
-    for (int k = 0; k < p.nk; ++k) {
-        const bool more = (k + 1) < p.nk;
-        if (more) {
-            advance();
-            gather(k + 1);
-        }
-        const unsigned char* As = smem + (k & 1) * (A_BYTES + B_BYTES);
+    auto compute = [&](int buf) {
+        const unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
         const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 fa[MT], fb[NT];
+            u32x4 fa[MT], fb[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = *(const uint4*)(As + lds_off(wm * WTM + i * 16 + fr, ks * 4 + fq));
+            for (int i = 0; i < MT; ++i) fa[i] = *(const u32x4*)(As + lds_off(wm * WTM + i * 16 + fr, ks * 4 + fq));
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = *(const uint4*)(Bs + lds_off(wn * WTN + j * 16 + fr, ks * 4 + fq));
+            for (int j = 0; j < NT; ++j) fb[j] = *(const u32x4*)(Bs + lds_off(wn * WTN + j * 16 + fr, ks * 4 + fq));
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) Frag<T>::mma(fa[i], fb[j], acc[i][j]);
         }
-        if (more) stage((k + 1) & 1);
+    };
+    // software pipeline: the global loads of tile k+1 are in flight while tile k feeds the MFMAs; one barrier per tile
+    gather(0);
+    stage(0);
+    __syncthreads();
+    for (int k = 0; k + 1 < p.nk; ++k) {
+        advance();
+        gather(k + 1);
+        compute(k & 1);
+        stage((k + 1) & 1);
         __syncthreads();
     }
+    compute((p.nk - 1) & 1);
+    __syncthreads();
 
     // ---- epilogue: per wave, one 16-row slab at a time through LDS
     float* ep = (float*)smem + wave * (16 * EP_STRIDE);
