@@ -156,9 +156,9 @@ def main():
         for k, (m, f, b, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
             print("%-10s n=%3d  %8.3f ms  %8.1f TFLOP/s  %8.1f GB/s(alg)" % (names.get(k, k), n, m, f / (m * 1e-3) / 1e12 if m else 0,
                                                                              b / (m * 1e-3) / 1e9 if m else 0), file=sys.stderr)
-        top = sorted(zip(ms, infos, range(len(ms))), key=lambda t: -t[0])[:25]
-        for m, (k, f, b), i in top:
-            print("  op %3d %-9s %7.3f ms %7.1f TF/s %7.1f GB/s" % (i, names.get(k, k), m, f / (m * 1e-3) / 1e12, b / (m * 1e-3) / 1e9), file=sys.stderr)
+        for i, (m, (k, f, b)) in enumerate(zip(ms, infos)):
+            print("  op %3d %-9s %7.3f ms %7.1f TF/s %7.1f GB/s  %8.2f GF %8.2f MB" % (i, names.get(k, k), m, f / (m * 1e-3) / 1e12,
+                                                                                     b / (m * 1e-3) / 1e9, f / 1e9, b / 1e6), file=sys.stderr)
 
     out = {"metric": "images/sec (fwd+decode+NMS) 640x640 bs64 per GPU", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",

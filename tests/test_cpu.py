@@ -1,0 +1,270 @@
+"""CPU-side tests (no GPU): the oracle against the reference-generated golden vectors, host logic (BN folding, weight
+packing, state_dict schema, sharding, detection all_gather over gloo) and the C ABI surface of libccnet_hip.so."""
+import ctypes
+import glob
+import importlib
+import math
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+FIXTURES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "net*_b*_*.npz")))
+KINDS = ("net", "net_deploy", "net_amff", "net_small_target")
+
+
+def _fx(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+# ----------------------------------------------------------------------------- oracle pinned to the reference's outputs
+@pytest.mark.parametrize("name", [f for f in FIXTURES if "_b1_" in f])
+def test_oracle_forward_matches_reference_fixture(name):
+    from ccnet_amd import synth
+    from oracle import ccnet_oracle as orc
+    fx = _fx(name)
+    kind, B, H, W = str(fx["kind"]), int(fx["B"]), int(fx["H"]), int(fx["W"])
+    net = importlib.import_module("ccnet_amd.network." + kind).Net(float(fx["depth"]), float(fx["width"]), int(fx["nc"]))
+    sd = synth.synth_state_dict(net.state_dict(), 0, kind)
+    assert abs(sum(synth.tensor_checksum(v) for v in sd.values()) - float(fx["weight_checksum"])) <= 1e-9 * abs(float(fx["weight_checksum"]))
+    x = synth.synth_images(B, H, W, 0)
+    taps = {}
+    heads = orc.forward(kind, sd, x, float(fx["depth"]), float(fx["width"]), "silu", taps)
+    for k, h in enumerate(heads):
+        ref = torch.from_numpy(fx["head%d" % k])
+        assert float((h - ref).abs().max() / ref.abs().max()) < 2e-5
+    for key in fx:
+        if key.startswith("tap_"):
+            t = taps[key[4:]][:, ::3, ::2, ::2]
+            ref = torch.from_numpy(fx[key])
+            assert float((t - ref).abs().max() / ref.abs().max().clamp_min(1e-12)) < 2e-5, key
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_oracle_decode_and_post_process_match_reference_fixture(name):
+    from oracle import ccnet_oracle as orc
+    fx = _fx(name)
+    H, W, nc = int(fx["H"]), int(fx["W"]), int(fx["nc"])
+    heads = []
+    while "head%d" % len(heads) in fx:
+        heads.append(torch.from_numpy(fx["head%d" % len(heads)]))
+    dec = orc.decode_outputs(heads, [H, W])
+    # sigmoid/exp come from ATen's CPU kernels: identical build -> identical bits; allow 1 ulp across machines
+    assert torch.allclose(dec, torch.from_numpy(fx["decoded"]), rtol=3e-7, atol=1e-9)
+    info = [list(map(int, r)) for r in fx["image_info"]]
+    got = orc.post_process(torch.from_numpy(fx["decoded"]), nc, [H, W], info, float(fx["conf"]), float(fx["nms"]))
+    counts = list(fx["det_counts"])
+    assert [g.shape[0] for g in got] == counts
+    assert np.array_equal(np.concatenate(got, 0), fx["dets"])
+
+
+def test_oracle_nms_known_answers():
+    from oracle import ccnet_oracle as orc
+
+    def run(boxes, scores, cls, thr):
+        return list(orc.batched_nms_reference(np.asarray(boxes, np.float32).reshape(-1, 4), np.asarray(scores, np.float32),
+                                              np.asarray(cls, np.float32), thr))
+
+    assert run([[0, 0, 1, 1], [0, 0, 1, 1]], [0.9, 0.8], [0, 0], 0.5) == [0]             # identical boxes
+    assert run([[0, 0, 1, 1], [1, 0, 2, 1]], [0.9, 0.8], [0, 0], 0.5) == [0, 1]          # touching, IoU 0
+    assert run([[0, 0, 2, 1], [0, 0, 1, 1]], [0.9, 0.8], [0, 0], 0.5) == [0, 1]          # IoU == thr is kept ('>')
+    assert run([[0, 0, 2, 1], [0, 0, 1, 1]], [0.8, 0.9], [0, 0], 0.49) == [1]            # order follows the scores
+    assert run([[0, 0, 1, 1], [0, 0, 1, 1]], [0.9, 0.8], [0, 1], 0.5) == [0, 1]          # other class never suppresses
+    assert run([[0, 0, 1, 1]] * 3, [0.7, 0.7, 0.7], [0, 0, 0], 0.5) == [0]               # ties: lower index first
+    assert run([[.5, .5, .5, .5]] * 2, [0.9, 0.8], [0, 0], 0.5) == [0, 1]                # zero area: NaN IoU keeps both
+    assert run([], [], [], 0.5) == []
+
+
+def test_oracle_post_process_empty_and_threshold_edge():
+    from oracle import ccnet_oracle as orc
+    pred = torch.zeros(2, 4, 11)
+    pred[..., 2:4] = 0.1
+    pred[0, 1, 4], pred[0, 1, 5] = 0.5, 1.0            # obj*cls == conf exactly: kept ('>=')
+    out = orc.post_process(pred, 6, [64, 64], [[0, 64, 64], [1, 64, 64]], 0.5, 0.4)
+    assert out[0].shape == (1, 7) and out[1].shape == (0, 7) and out[1].dtype == np.float32
+    assert orc.post_process(torch.zeros(1, 0, 11), 6, [64, 64], [[0, 64, 64]]) == [None]
+
+
+# ----------------------------------------------------------------------------- synthetic data generator
+def test_synth_is_deterministic_and_keyed():
+    from ccnet_amd import synth
+    a = synth.synth_tensor("dark2.0.conv.conv.weight", (64, 128, 3, 3), 0)
+    b = synth.synth_tensor("dark2.0.conv.conv.weight", (64, 128, 3, 3), 0)
+    c = synth.synth_tensor("dark3.0.conv.conv.weight", (64, 128, 3, 3), 0)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(float(a.std()) * math.sqrt(128 * 9) - 1.7) < 0.05
+    x = synth.synth_images(2, 32, 32, 0)
+    assert torch.equal(x[1], synth.synth_images(3, 32, 32, 0)[1])
+    assert abs(float(x.mean())) < 0.05 and abs(float(x.std()) - 1) < 0.05
+
+
+# ----------------------------------------------------------------------------- state_dict schema (drop-in boundary)
+@pytest.mark.parametrize("kind,nkeys", [("net", 639), ("net_deploy", 471), ("net_amff", 535), ("net_small_target", 582)])
+def test_state_dict_schema_matches_survey(kind, nkeys):
+    net = importlib.import_module("ccnet_amd.network." + kind).Net(0.33, 0.5, 6)
+    sd = net.state_dict()
+    assert len(sd) == nkeys
+    assert tuple(sd["cls_preds.0.weight"].shape) == (6, 128, 1, 1) and tuple(sd["obj_preds.2.bias"].shape) == (1,)
+    if kind == "net":
+        assert tuple(sd["stem.conv.conv.weight"].shape) == (32, 12, 3, 3)
+        assert tuple(sd["dark5.2.transformer.encoder.layers.0.self_attn.in_proj_weight"].shape) == (768, 256)
+        assert "dark5.2.transformer.decoder.layers.0.multihead_attn.out_proj.bias" in sd
+    else:
+        assert tuple(sd["stem.conv.weight"].shape) == (32, 3, 6, 6) and "stem.bn.running_var" in sd
+    # the fixtures' calibrated BN statistics cover exactly this model's BN layers
+    with np.load(os.path.join(GOLD, "bn_calib_%s.npz" % kind)) as z:
+        assert set(z.files) == {k for k in sd if k.endswith("running_mean") or k.endswith("running_var")}
+
+
+def test_load_model_weights_contract(tmp_path):
+    from ccnet_amd.network.net_deploy import Net
+    from ccnet_amd.utils.util import load_model_weights
+    src = Net(0.33, 0.5, 6)
+    sd = {k: torch.full_like(v, 0.25) if v.is_floating_point() else v for k, v in src.state_dict().items()}
+    sd["cls_preds.0.weight"] = torch.zeros(80, 128, 1, 1)  # wrong shape: skipped, not an error
+    path = str(tmp_path / "model_best.pth")
+    torch.save({"epoch": 3, "model": sd, "ap50": 0.5, "ap5095": 0.321}, path)
+    dst = Net(0.33, 0.5, 6)
+    before = dst.state_dict()["cls_preds.0.weight"].clone()
+    dst, ap = load_model_weights(dst, path, torch.device("cpu"))
+    assert ap == 0.321
+    assert float(dst.state_dict()["stem.conv.weight"].mean()) == 0.25
+    assert torch.equal(dst.state_dict()["cls_preds.0.weight"], before)
+    sd["not.a.key"] = torch.zeros(1)
+    torch.save({"epoch": 3, "model": sd, "ap50": 0.5, "ap5095": 0.3}, path)
+    with pytest.raises(KeyError):
+        load_model_weights(Net(0.33, 0.5, 6), path, torch.device("cpu"))
+
+
+def test_net_constructor_errors_and_cpu_refusal():
+    from ccnet_amd.network.net_deploy import Net
+    from ccnet_amd.utils import bbox
+    from ccnet_amd.utils.initialization import model_initializer
+    with pytest.raises(AttributeError):
+        Net(0.33, 0.5, 6, act="gelu")
+    net = Net(*model_initializer("s"), 6)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 64, 64))      # CPU tensor: no silent fallback
+    with pytest.raises(RuntimeError):
+        net.train()
+    with pytest.raises(RuntimeError):
+        bbox.decode_outputs([torch.zeros(1, 11, 8, 8)], [64, 64])
+    with pytest.raises(RuntimeError):
+        bbox.post_process(torch.zeros(1, 10, 11), 6, [64, 64], [[0, 64, 64]])
+    assert model_initializer("l") == (1.0, 1.0) and model_initializer("tiny") == (0.33, 0.375)
+
+
+# ----------------------------------------------------------------------------- host-side weight math
+def test_fold_bn_and_s2d_identity():
+    from ccnet_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 8, 12, 10, generator=g)
+    w = torch.randn(16, 32, 3, 3, generator=g) * 0.1
+    bn = (torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g), torch.randn(16, generator=g), torch.rand(16, generator=g) + 0.5)
+    s2d = torch.cat((x[..., ::2, ::2], x[..., ::2, 1::2], x[..., 1::2, ::2], x[..., 1::2, 1::2]), 1)
+    ref = F.batch_norm(F.conv2d(s2d, w, None, 1, 1), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    wf, bf = ops.fold_bn(w, bn)
+    got = F.conv2d(x.double(), ops.s2d_to_6x6(wf), bf, 2, 2)
+    assert float((got.float() - ref).abs().max()) < 1e-5
+
+
+def test_pack_layouts():
+    from ccnet_amd import ops, _lib
+    w6 = torch.arange(2 * 3 * 6 * 6, dtype=torch.float64).reshape(2, 3, 6, 6)
+    wp, bp = ops.pack_stem(w6, torch.zeros(2), "cpu")
+    assert wp.shape == (2, 160)
+    assert float(wp[1, (2 * 6 + 4) * 8 + 5]) == float(w6[1, 2, 4, 5]) and float(wp[0, 6]) == 0 and float(wp[0, 159]) == 0
+    cp, kp = _lib.conv_pack_dims(_lib.BF16, 128, 1152)
+    assert (cp, kp) == (128, 1152)
+    assert _lib.conv_pack_dims(_lib.F32, 5, 128) == (16, 128)
+    assert _lib.conv_pack_dims(_lib.BF16, 200, 100) == (256, 128)
+    w = torch.randn(5, 8, 3, 3)
+    pc = ops.PackedConv(w, torch.zeros(5), _lib.F32, "cpu")
+    assert pc.weight.shape == (16, 96) and torch.equal(pc.weight[:5, :72].reshape(5, 3, 3, 8).permute(0, 3, 1, 2), w)
+    assert float(pc.weight[5:].abs().max()) == 0 and float(pc.weight[:, 72:].abs().max()) == 0
+
+
+# ----------------------------------------------------------------------------- C ABI surface
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ccnet_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(ccnet_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    lib = ctypes.CDLL(os.path.join(ROOT, "ccnet_amd", "libccnet_hip.so"))
+    for n in names:
+        assert hasattr(lib, n), "libccnet_hip.so does not export %s" % n
+
+
+def test_c_abi_validates_before_launching():
+    """Bad descriptors are rejected on the host with a message; nothing reaches a GPU (there is none here)."""
+    from ccnet_amd import _lib
+    L = _lib.lib()
+    assert L.ccnet_version() >= 100
+    d = _lib.ConvDesc()
+    d.dtype, d.out_dtype, d.nseg = 1, 1, 3
+    assert L.ccnet_conv2d(ctypes.byref(d), None) == -1 and b"nseg" in L.ccnet_last_error()
+    assert L.ccnet_layernorm(None, None, None, None, None, 1, 4, 256, 1e-5, None) == -1
+    assert L.ccnet_nms_workspace_bytes(2, 100) > 2 * 128 * 2 * 8
+    h = ctypes.c_void_p()
+    assert L.ccnet_plan_begin(ctypes.byref(h)) == 0
+    assert L.ccnet_plan_begin(ctypes.byref(ctypes.c_void_p())) == -1          # one open plan per thread
+    assert L.ccnet_plan_end() == 0 and L.ccnet_plan_num_ops(h) == 0
+    assert L.ccnet_plan_end() == -1
+    L.ccnet_plan_destroy(h)
+
+
+# ----------------------------------------------------------------------------- multi-GPU layer on gloo
+def test_shard_range_partitions_batch():
+    from ccnet_amd.parallel import shard_range
+    for total, world in [(256, 8), (10, 4), (3, 8), (64, 1)]:
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+def _gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from ccnet_amd.parallel import all_gather_detections
+    rng = np.random.RandomState(rank)
+    local = [rng.rand(n, 7).astype(np.float32) for n in ([3, 0] if rank == 0 else [5])]
+    if rank == 1:
+        local.append(None)
+    out = all_gather_detections(local)
+    q.put((rank, [None if o is None else o.copy() for o in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_detections_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    exp0 = [np.random.RandomState(0).rand(3, 7).astype(np.float32)]
+    r0 = np.random.RandomState(0)
+    e = [r0.rand(3, 7).astype(np.float32), r0.rand(0, 7).astype(np.float32)]
+    r1 = np.random.RandomState(1)
+    e += [r1.rand(5, 7).astype(np.float32), None]
+    for rank in (0, 1):
+        got = res[rank]
+        assert len(got) == 4
+        for a, b in zip(got, e):
+            assert (a is None and b is None) or (a.shape == b.shape and np.array_equal(a, b))
