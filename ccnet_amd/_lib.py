@@ -9,7 +9,7 @@ F32, BF16 = 0, 1
 ACT = {"none": 0, None: 0, "silu": 1, "relu": 2, "relu6": 3, "lrelu": 4}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libccnet_hip.so")
+LIB_PATH = os.environ.get("CCNET_HIP_LIB") or os.path.join(_HERE, "libccnet_hip.so")
 
 
 class Slice(C.Structure):

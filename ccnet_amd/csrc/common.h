@@ -91,13 +91,23 @@ template <typename T> __device__ __forceinline__ void store1(T* p, float v);
 template <> __device__ __forceinline__ void store1<__bf16>(__bf16* p, float v) { *p = (__bf16)v; }
 template <> __device__ __forceinline__ void store1<float>(float* p, float v) { *p = v; }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// 1 / (1 + e^-x) from v_exp_f32 and v_rcp_f32 (both ~1 ulp): 5 VALU instructions.  A true IEEE division here costs ~15
+// instructions per element and made the conv epilogue as expensive as its MFMAs.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+template <int ACT>
+__device__ __forceinline__ float act_fn(float x) {
+    if constexpr (ACT == CCNET_ACT_SILU) return x * sigmoidf_(x);
+    else if constexpr (ACT == CCNET_ACT_RELU) return fmaxf(x, 0.0f);
+    else if constexpr (ACT == CCNET_ACT_RELU6) return fminf(fmaxf(x, 0.0f), 6.0f);
+    else if constexpr (ACT == CCNET_ACT_LRELU) return x > 0.0f ? x : 0.1f * x;
+    else return x;
+}
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {
-        case CCNET_ACT_SILU: return x * sigmoidf_(x);
-        case CCNET_ACT_RELU: return fmaxf(x, 0.0f);
-        case CCNET_ACT_RELU6: return fminf(fmaxf(x, 0.0f), 6.0f);
-        case CCNET_ACT_LRELU: return x > 0.0f ? x : 0.1f * x;
+        case CCNET_ACT_SILU: return act_fn<CCNET_ACT_SILU>(x);
+        case CCNET_ACT_RELU: return act_fn<CCNET_ACT_RELU>(x);
+        case CCNET_ACT_RELU6: return act_fn<CCNET_ACT_RELU6>(x);
+        case CCNET_ACT_LRELU: return act_fn<CCNET_ACT_LRELU>(x);
         default: return x;
     }
 }

@@ -1,16 +1,27 @@
-// BN-folded NHWC implicit-GEMM convolution on gfx950 MFMA.
+// BN-folded NHWC implicit-GEMM convolution on gfx950 MFMA -- persistent, software-pipelined kernel.
 //
-// GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = kh*kw*Ctot.  A (pixels x K) is gathered on the fly from
-// one or two NHWC channel slices (second slice = torch.cat, shift = nearest upsampling), B is the packed
-// weight [Cout_pad][Kpad].  Block = 256 threads (4 waves), tile 128 x BN x 128 bytes of K (64 bf16 / 32 f32),
-// LDS double buffered, next tile prefetched into registers while the current one feeds the MFMAs
-// (register staging because out-of-image taps must read as zero).
-// LDS rows are 128 B = 8 chunks of 16 B; chunk c of row r lives at chunk c ^ ((r>>1)&7), which makes both the
-// ds_write_b128 fill and the ds_read_b128 fragment reads bank-conflict free for the gfx950 lane groups.
-// bf16: v_mfma_f32_16x16x32_bf16; fp32: v_mfma_f32_16x16x4_f32 (exact fp32, k order permuted identically
-// for A and B).  Epilogue: bias + activation (+ residual) through a wave-private LDS transpose so that global
-// stores are 16 B per lane along the channel axis.
+// GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = kh*kw*Ctot.  A (pixels x K) is gathered on the fly from one or
+// two NHWC channel slices (second slice = torch.cat, shift = nearest upsampling), B is the packed weight [Cout_pad][Kpad].
+// Block = 256 threads (4 waves), tile 128 x BN x 128 bytes of K per step (64 bf16 / 32 f32).
+//
+// Pipeline: a block walks a strided list of M tiles; the (tile, K-step) pairs form ONE flattened sequence with two LDS
+// buffers.  In step j the block (1) issues the global loads of step j+1 -- which may already belong to the next tile --,
+// (2) if step j-1 finished a tile, runs that tile's epilogue (registers -> global) while those loads fly,
+// (3) feeds step j's MFMAs, (4) writes step j+1's registers to the idle buffer, (5) one barrier.  So neither the
+// prologue of a tile nor its epilogue leaves the memory pipe empty, which is what the thin 1x1 layers (1-2 K steps)
+// need, and the deep 3x3 layers pay one prologue per block instead of one per tile.
+//
+// Gather cost: per tile each thread precomputes, for its 4 rows, a byte pointer to tap (0,0) per input segment and a
+// 64-bit tap-validity mask; a K step then costs a shift/test, a 64-bit add and a select per row.  Out-of-image taps load
+// a safe address and are zeroed when written to LDS (no exec-mask branches, loads stay in flight across the MFMAs).
+// LDS rows are 128 B = 8 chunks of 16 B; chunk c of row r lives at c ^ ((r>>1)&7): conflict free for the gfx950
+// ds_read_b128 lane groups and for the ds_write_b128 fill.  bf16: v_mfma_f32_16x16x32_bf16; fp32: v_mfma_f32_16x16x4_f32
+// (exact fp32, k order permuted identically for A and B).  The weights are the MFMA "A" operand, so each lane ends up
+// with 4 consecutive channels of one pixel per accumulator tile: the epilogue (bias + activation + residual) is
+// register-only and stores 8 B (bf16) / 16 B (fp32) per lane -- an LDS-transposed epilogue cost as much as all MFMAs.
 #include "common.h"
+
+int ccnet_conv2d_generic(const ccnet_conv_desc* d, ccnet_stream stream);  // conv_generic.hip
 
 namespace {
 
@@ -18,31 +29,31 @@ constexpr int BM = 128;
 constexpr int BKB = 128;  // bytes of K per row per step
 constexpr int NTHREADS = 256;
 
-struct SegP {
-    const unsigned char* ptr;
-    int ldc, coff, C, shift, Hs, Ws;
+// native vector type for everything staged through registers (arrays of HIP's uint4 struct end up in scratch/LDS)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct SegQ {
+    const unsigned char* ptr;  // first element of the slice (channel offset applied)
+    unsigned ldcB;             // pixel stride in bytes
+    int shift, Hs, Ws;
 };
 
-struct ConvP {
-    SegP seg[2];
-    int Ctot, C0;
-    int B, H, W, kh, kw, stride, pad, Ho, Wo, Cout;
-    long long M;
+struct ConvQ {
+    SegQ seg[2];
+    int nseg, Ctot, C0;
+    int H, W, kh, kw, stride, pad, Ho, Wo, Cout;
+    unsigned M, ntiles;
+    unsigned magicW, shiftW, magicH, shiftH;  // n / Wo, n / Ho by multiply-high
     const unsigned char* weight;
-    int Kpad;  // elements
-    int nk;    // K steps
+    int Kpad, nk;
     const float* bias;
     int act;
     const unsigned char* res_ptr;
     int res_ldc, res_coff;
     unsigned char* out_ptr;
     int out_ldc, out_coff;
-    int vec_out;  // 1: channel groups of 8 are aligned in out/residual
+    int vec_out;
 };
-
-// native vector type for everything staged through registers (HIP's uint4 is a struct wrapping a union, which LLVM
-// sometimes leaves in scratch when held in small arrays)
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T> struct Frag;
 template <> struct Frag<__bf16> {
@@ -61,90 +72,121 @@ template <> struct Frag<float> {
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BKB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned magic, unsigned shift) { return (__umulhi(n, magic) + n) >> shift; }
 
-template <typename T, typename OutT, int BN, int WM, int WN>
-__global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvP p) {
+#ifndef CC_AB
+#define CC_AB 0  // perf-ablation bit mask (debug builds only): 1 no gather, 2 no stage, 4 no barrier, 8 no LDS reads,
+                 // 16 no epilogue, 32 epilogue without stores, 64 stores to a fixed region
+#endif
+
+// ACT: activation compiled into the epilogue (CCNET_ACT_*), or ACT_RUNTIME to branch on p.act per element.
+constexpr int ACT_RUNTIME = -1;
+
+template <typename T, typename OutT, int BN, int WM, int WN, int ACT>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) {
     constexpr int ES = (int)sizeof(T);
-    constexpr int EPC = 16 / ES;   // elements per 16-B chunk
-    constexpr int BK = BKB / ES;   // elements of K per step
+    constexpr int EPC = 16 / ES;  // elements per 16-B chunk
+    constexpr int BK = BKB / ES;  // elements of K per step
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
-    constexpr int A_LOADS = BM / 32;                   // 4
-    constexpr int B_LOADS = (BN >= 32) ? BN / 32 : 1;  // rows of B per thread
-    constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;
-    constexpr int EP_STRIDE = WTN + 4;  // floats per row in the epilogue staging tile
-    constexpr int EP_BYTES = 4 * 16 * EP_STRIDE * 4;
-    constexpr int SMEM = (2 * (A_BYTES + B_BYTES) > EP_BYTES) ? 2 * (A_BYTES + B_BYTES) : EP_BYTES;
-    __shared__ __align__(16) unsigned char smem[SMEM];
+    constexpr int A_LOADS = BM / 32;
+    constexpr int B_LOADS = (BN >= 32) ? BN / 32 : 1;
+    constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB, BUF_BYTES = A_BYTES + B_BYTES;
+    __shared__ __align__(16) unsigned char smem[2 * BUF_BYTES];
+
+    const unsigned tile0 = blockIdx.x, tstride = gridDim.x;
+    if (tile0 >= p.ntiles) return;
+    const unsigned my_tiles = (p.ntiles - tile0 + tstride - 1) / tstride;
+    const unsigned total = my_tiles * (unsigned)p.nk;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const long long m0 = (long long)blockIdx.x * BM;
+    const int fr = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.y * BN;
-
-    // ---- per-thread gather state: chunk column `lc`, rows lr + 32*i
-    const int lc = t & 7, lr = t >> 3;
-    int iy0[A_LOADS], ix0[A_LOADS], bb[A_LOADS];
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-        long long m = m0 + lr + 32 * i;
-        if (m < p.M) {
-            int ox = (int)(m % p.Wo);
-            long long r = m / p.Wo;
-            int oy = (int)(r % p.Ho);
-            bb[i] = (int)(r / p.Ho);
-            iy0[i] = oy * p.stride - p.pad;
-            ix0[i] = ox * p.stride - p.pad;
-        } else {
-            bb[i] = 0; iy0[i] = -(1 << 28); ix0[i] = 0;  // row past M: every tap is out of the image
-        }
-    }
-    // K cursor of this thread's chunk: channel c within the concatenated input, tap (ky, kx)
-    int kc = lc * EPC;
-    int tap = kc / p.Ctot;
-    int c = kc - tap * p.Ctot;
-    int ky = tap / p.kw, kx = tap - ky * p.kw;
+    const int lc = t & 7, lr = t >> 3;  // this thread's 16-B chunk column and first row of the staged tiles
     const bool b_active = (BN >= 32) || (t < BN * 8);
-    const unsigned char* wrow = p.weight + ((size_t)(n0 + lr) * p.Kpad + lc * EPC) * ES;
+    const unsigned char* wrow = p.weight + ((size_t)(n0 + (b_active ? lr : 0)) * p.Kpad + lc * EPC) * ES;
 
+    // K cursor of this thread's chunk at step 0 of a tile
+    int c_init, ky_init, kx_init;
+    {
+        const int kc = lc * EPC;
+        const int tap = kc / p.Ctot;
+        c_init = kc - tap * p.Ctot;
+        ky_init = tap / p.kw;
+        kx_init = tap - ky_init * p.kw;
+    }
+
+    // ---- gather side state (runs one step ahead of the MFMAs)
+    const unsigned char* rowptr[2][A_LOADS];
+    unsigned long long rmask[A_LOADS];
+    unsigned g_tile = tile0;
+    int g_k = 0, c = c_init, ky = ky_init, kx = kx_init;
     u32x4 ra[A_LOADS], rb[B_LOADS];
     unsigned okbits = 0u;
-    auto gather = [&](int kstep) {
-        const int s = (c >= p.C0) ? 1 : 0;
-        const SegP& sg = p.seg[s];
-        const int cs = c - (s ? p.C0 : 0);
-        const bool tap_ok = ky < p.kh;
-        const unsigned char* sbase = sg.ptr + (size_t)(sg.coff + cs) * ES;
+
+    auto setup_rows = [&](unsigned tile) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const unsigned m = tile * BM + lr + 32 * i;
+            const bool valid = m < p.M;
+            const unsigned mm = valid ? m : 0u;
+            const unsigned q1 = fastdiv(mm, p.magicW, p.shiftW);
+            const int ox = (int)(mm - q1 * (unsigned)p.Wo);
+            const unsigned b = fastdiv(q1, p.magicH, p.shiftH);
+            const int oy = (int)(q1 - b * (unsigned)p.Ho);
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const SegQ& sg = p.seg[s];
+                const long long pix = ((long long)b * sg.Hs + (iy0 >> sg.shift)) * sg.Ws + (ix0 >> sg.shift);
+                rowptr[s][i] = sg.ptr + pix * (long long)sg.ldcB;
+            }
+            unsigned xbits = 0u;
+            for (int x = 0; x < p.kw; ++x) xbits |= ((unsigned)(ix0 + x) < (unsigned)p.W ? 1u : 0u) << x;
+            unsigned long long mk = 0ull;
+            for (int y = 0; y < p.kh; ++y)
+                if ((unsigned)(iy0 + y) < (unsigned)p.H) mk |= (unsigned long long)xbits << (y * p.kw);
+            rmask[i] = valid ? mk : 0ull;
+        }
+    };
+    auto gather = [&]() {
+        const bool s1 = c >= p.C0;  // only possible with two segments (C0 == Ctot otherwise)
+        const int cs = c - (s1 ? p.C0 : 0);
+        const unsigned ldcB = s1 ? p.seg[1].ldcB : p.seg[0].ldcB;
+        const unsigned char* safe = s1 ? p.seg[1].ptr : p.seg[0].ptr;
+        const unsigned off = (unsigned)(ky * p.W + kx) * ldcB + (unsigned)cs * ES;
+        const int tap = ky * p.kw + kx;
+        const bool tap_ok = ky < p.kh;  // false in the zero-padded tail of K
         okbits = 0u;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-            const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            // branch-free: out-of-image taps load a clamped (always mapped) pixel and are zeroed when the tile is
-            // written to LDS, so the loads of a K step issue back to back and stay in flight across the MFMAs
-            const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
-            const size_t pix = ((size_t)bb[i] * sg.Hs + (iyc >> sg.shift)) * sg.Ws + (ixc >> sg.shift);
-            ra[i] = *(const u32x4*)(sbase + pix * sg.ldc * ES);
+            const bool ok = tap_ok && ((rmask[i] >> tap) & 1ull);
+            const unsigned char* ptr = (s1 ? rowptr[1][i] : rowptr[0][i]) + off;
+            ra[i] = *(const u32x4*)(ok ? ptr : safe);
             okbits |= (ok ? 1u : 0u) << i;
         }
-        if constexpr (BN >= 32) {
+        const size_t koff = (size_t)g_k * BK * ES;
 #pragma unroll
-            for (int i = 0; i < B_LOADS; ++i)
-                rb[i] = *(const u32x4*)(wrow + ((size_t)(32 * i) * p.Kpad + (size_t)kstep * BK) * ES);
-        } else {
-            // BN == 16: only 128 threads own a weight chunk; the others re-read row 0's chunk and never store it
-            rb[0] = *(const u32x4*)((b_active ? wrow : wrow - (size_t)lr * p.Kpad * ES) + (size_t)kstep * BK * ES);
-        }
+        for (int i = 0; i < B_LOADS; ++i) rb[i] = *(const u32x4*)(wrow + (size_t)(32 * i) * p.Kpad * ES + koff);
     };
+    // move the gather cursor to the next (tile, K step)
     auto advance = [&]() {
-        c += BK;
-        while (c >= p.Ctot) {
-            c -= p.Ctot;
-            if (++kx == p.kw) { kx = 0; ++ky; }
+        if (++g_k == p.nk) {
+            g_k = 0;
+            g_tile += tstride;
+            c = c_init; ky = ky_init; kx = kx_init;
+            setup_rows(g_tile);
+        } else {
+            c += BK;
+            while (c >= p.Ctot) {
+                c -= p.Ctot;
+                if (++kx == p.kw) { kx = 0; ++ky; }
+            }
         }
     };
     auto stage = [&](int buf) {
-        unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
+        unsigned char* As = smem + buf * BUF_BYTES;
         unsigned char* Bs = As + A_BYTES;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i)
@@ -161,101 +203,207 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int fr = lane & 15, fq = lane >> 4;
     auto compute = [&](int buf) {
-        const unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
+        const unsigned char* As = smem + buf * BUF_BYTES;
         const unsigned char* Bs = As + A_BYTES;
+        // both halves of the K step are requested up front: the second half's LDS latency hides behind the first MFMAs
+        u32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+#if (CC_AB & 8)
+        // ablation only: MFMAs on whatever the staging registers hold, no LDS traffic
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4 fa[MT], fb[NT];
+        for (int i = 0; i < MT; ++i) { fa0[i] = ra[i % A_LOADS]; fa1[i] = ra[(i + 1) % A_LOADS]; }
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = *(const u32x4*)(As + lds_off(wm * WTM + i * 16 + fr, ks * 4 + fq));
+        for (int j = 0; j < NT; ++j) { fb0[j] = rb[j % B_LOADS]; fb1[j] = rb[(j + 1) % B_LOADS]; }
+        if (false)
+#endif
+        {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = *(const u32x4*)(Bs + lds_off(wn * WTN + j * 16 + fr, ks * 4 + fq));
+        for (int i = 0; i < MT; ++i) fa0[i] = *(const u32x4*)(As + lds_off(wm * WTM + i * 16 + fr, fq));
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+        for (int j = 0; j < NT; ++j) fb0[j] = *(const u32x4*)(Bs + lds_off(wn * WTN + j * 16 + fr, fq));
 #pragma unroll
-                for (int j = 0; j < NT; ++j) Frag<T>::mma(fa[i], fb[j], acc[i][j]);
+        for (int i = 0; i < MT; ++i) fa1[i] = *(const u32x4*)(As + lds_off(wm * WTM + i * 16 + fr, 4 + fq));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb1[j] = *(const u32x4*)(Bs + lds_off(wn * WTN + j * 16 + fr, 4 + fq));
         }
+        // keep the 16 LDS reads ahead of the MFMAs (the scheduler otherwise sinks each read next to its first use and
+        // exposes the LDS latency four times per step)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) Frag<T>::mma(fb0[j], fa0[i], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) Frag<T>::mma(fb1[j], fa1[i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
     };
-    // software pipeline: the global loads of tile k+1 are in flight while tile k feeds the MFMAs; one barrier per tile
-    gather(0);
+
+    // The MFMAs run with the weights as the "A" operand, so a lane's 4 accumulator registers of tile (i, j) are 4
+    // CONSECUTIVE CHANNELS (n = nbase + j*16 + fq*4 + r) of ONE pixel (m = ... + i*16 + fr): bias + activation
+    // (+ residual) happen in registers and each lane stores 4 channels (8 B bf16 / 16 B fp32) straight to global --
+    // no LDS round trip, no barrier, and the epilogue overlaps the next tile's loads that are already in flight.
+    const int nbase = n0 + wn * WTN + fq * 4;
+    float breg[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nbase + j * 16 + r;
+            breg[j][r] = (p.bias && n < p.Cout) ? p.bias[n] : 0.0f;
+        }
+    auto epilogue = [&](unsigned tile) {
+#if (CC_AB & 16)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+        if (false)
+#endif
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const unsigned m = tile * BM + wm * WTM + i * 16 + fr;
+            if (m < p.M) {
+#if (CC_AB & 64)
+                unsigned char* orow = p.out_ptr + ((size_t)(blockIdx.x * BM + wm * WTM + i * 16 + fr) * p.out_ldc + p.out_coff) * sizeof(OutT);
+#else
+                unsigned char* orow = p.out_ptr + ((size_t)m * p.out_ldc + p.out_coff) * sizeof(OutT);
+#endif
+                const unsigned char* rrow = p.res_ptr ? p.res_ptr + ((size_t)m * p.res_ldc + p.res_coff) * ES : nullptr;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int n = nbase + j * 16;
+                    if (n >= p.Cout) continue;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = acc[i][j][r] + breg[j][r];
+                        if constexpr (ACT == ACT_RUNTIME) v[r] = apply_act(x, p.act);
+                        else v[r] = act_fn<ACT>(x);
+                    }
+                    if (p.vec_out && n + 4 <= p.Cout) {
+                        if (rrow) {
+                            if constexpr (ES == 2) {
+                                const uint2 rv = *(const uint2*)(rrow + (size_t)n * 2);
+                                v[0] += bf16_bits_to_f32(rv.x & 0xFFFFu); v[1] += bf16_bits_to_f32(rv.x >> 16);
+                                v[2] += bf16_bits_to_f32(rv.y & 0xFFFFu); v[3] += bf16_bits_to_f32(rv.y >> 16);
+                            } else {
+                                const float4 rv = *(const float4*)(rrow + (size_t)n * 4);
+                                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                            }
+                        }
+#if (CC_AB & 32)
+                        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+                        if (false)
+#endif
+                        if constexpr (sizeof(OutT) == 2) {
+                            *(uint2*)(orow + (size_t)n * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        } else {
+                            *(float4*)(orow + (size_t)n * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                        }
+                    } else {
+                        for (int r = 0; r < 4 && n + r < p.Cout; ++r) {
+                            float x = v[r];
+                            if (rrow) x += load1<T>((const T*)rrow + n + r);
+                            store1<OutT>((OutT*)orow + n + r, x);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    setup_rows(g_tile);
+    gather();
     stage(0);
     __syncthreads();
-    for (int k = 0; k + 1 < p.nk; ++k) {
-        advance();
-        gather(k + 1);
-        compute(k & 1);
-        stage((k + 1) & 1);
-        __syncthreads();
-    }
-    compute((p.nk - 1) & 1);
-    __syncthreads();
-
-    // ---- epilogue: per wave, one 16-row slab at a time through LDS
-    float* ep = (float*)smem + wave * (16 * EP_STRIDE);
-    constexpr int UPR = WTN / 8;          // 8-channel units per row
-    constexpr int UNITS = 16 * UPR;       // per slab
-    const int nbase = n0 + wn * WTN;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ep[(fq * 4 + r) * EP_STRIDE + j * 16 + fr] = acc[i][j][r];
-        __syncthreads();
-        for (int u = lane; u < UNITS; u += 64) {
-            const int row = u / UPR, cu = u - row * UPR;
-            const long long m = m0 + wm * WTM + i * 16 + row;
-            const int n = nbase + cu * 8;
-            if (m >= p.M || n >= p.Cout) continue;
-            float v[8];
-            const float4 x0 = *(const float4*)(ep + row * EP_STRIDE + cu * 8);
-            const float4 x1 = *(const float4*)(ep + row * EP_STRIDE + cu * 8 + 4);
-            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-            const int nv = (p.Cout - n) < 8 ? (p.Cout - n) : 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float b = (p.bias && e < nv) ? p.bias[n + e] : 0.0f;
-                v[e] = apply_act(v[e] + b, p.act);
-            }
-            unsigned char* optr = p.out_ptr + ((size_t)m * p.out_ldc + p.out_coff + n) * sizeof(OutT);
-            if (p.vec_out && nv == 8) {
-                if (p.res_ptr) {
-                    float rv[8];
-                    Chan8<T>::load(p.res_ptr + ((size_t)m * p.res_ldc + p.res_coff + n) * ES, rv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
-                }
-                Chan8<OutT>::store(optr, v);
-            } else {
-                for (int e = 0; e < nv; ++e) {
-                    float x = v[e];
-                    if (p.res_ptr) x += load1<T>((const T*)(p.res_ptr + ((size_t)m * p.res_ldc + p.res_coff + n + e) * ES));
-                    store1<OutT>((OutT*)optr + e, x);
-                }
-            }
+    unsigned c_tile = tile0;  // tile the MFMAs are working on
+    int c_k = 0;
+    bool pending = false;
+    unsigned pend_tile = 0;
+    for (unsigned j = 0;; ++j) {  // one extra trip drains the last tile's epilogue (single inlined epilogue body)
+        const bool has_next = (j + 1) < total;
+        if (has_next) {
+            advance();
+            if (!(CC_AB & 1)) gather();
+        }
+        if (pending) {
+            epilogue(pend_tile);
+            pending = false;
+        }
+        if (j == total) break;
+        compute((int)(j & 1));
+        if (has_next && !(CC_AB & 2)) stage((int)((j + 1) & 1));
+        if (!(CC_AB & 4)) __syncthreads();
+        if (++c_k == p.nk) {
+            c_k = 0;
+            pending = true;
+            pend_tile = c_tile;
+            c_tile += tstride;
         }
     }
 }
 
 int pick_bn(int Cout) { return Cout <= 16 ? 16 : Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128; }
 
-template <typename T, typename OutT>
-int launch(const ConvP& p, int bn, hipStream_t st) {
-    dim3 block(NTHREADS);
-    long long mt = (p.M + BM - 1) / BM;
-    int coutp = ((p.Cout + bn - 1) / bn) * bn;
-    dim3 grid((unsigned)mt, (unsigned)(coutp / bn));
-    switch (bn) {
-        case 128: hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, 128, 2, 2>), grid, block, 0, st, p); break;
-        case 64: hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, 64, 2, 2>), grid, block, 0, st, p); break;
-        case 32: hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, 32, 4, 1>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((conv_igemm_kernel<T, OutT, 16, 4, 1>), grid, block, 0, st, p); break;
+void magic_div(unsigned d, unsigned* magic, unsigned* shift) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    *shift = s;
+    *magic = (unsigned)((((1ull << s) - d) << 32) / d + 1);
+}
+
+template <typename T, typename OutT, int BN, int WM, int WN, int ACT>
+int resident_blocks() {
+    auto kernel = conv_igemm_kernel<T, OutT, BN, WM, WN, ACT>;
+    // blocks of this instantiation that fit on the chip at once (cached per instantiation and device)
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (cached[dev] == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, NTHREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cached[dev] = per_cu * cus;
     }
+    return cached[dev];
+}
+
+template <typename T, typename OutT, int BN, int WM, int WN, int ACT>
+int launch_act(const ConvQ& p, hipStream_t st) {
+    auto kernel = conv_igemm_kernel<T, OutT, BN, WM, WN, ACT>;
+    const int gy = (p.Cout + BN - 1) / BN;
+    int gx = resident_blocks<T, OutT, BN, WM, WN, ACT>() / gy;
+    if (gx < 1) gx = 1;
+    if ((unsigned)gx > p.ntiles) gx = (int)p.ntiles;
+    hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(NTHREADS), 0, st, p);
     CC_LAUNCH_CHECK();
     return CCNET_OK;
+}
+
+template <typename T, typename OutT, int BN, int WM, int WN>
+int launch_bn(const ConvQ& p, hipStream_t st) {
+    // SiLU (every BaseConv) and identity (prediction / attention / linear layers) get their own code; the rest branch
+    if (p.act == CCNET_ACT_SILU) return launch_act<T, OutT, BN, WM, WN, CCNET_ACT_SILU>(p, st);
+    if (p.act == CCNET_ACT_NONE) return launch_act<T, OutT, BN, WM, WN, CCNET_ACT_NONE>(p, st);
+    return launch_act<T, OutT, BN, WM, WN, ACT_RUNTIME>(p, st);
+}
+
+template <typename T, typename OutT>
+int launch(const ConvQ& p, int bn, hipStream_t st) {
+    switch (bn) {
+        case 128: return launch_bn<T, OutT, 128, 2, 2>(p, st);
+        case 64: return launch_bn<T, OutT, 64, 2, 2>(p, st);
+        case 32: return launch_bn<T, OutT, 32, 4, 1>(p, st);
+        default: return launch_bn<T, OutT, 16, 4, 1>(p, st);
+    }
 }
 
 }  // namespace
@@ -278,28 +426,46 @@ extern "C" int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream) {
     CC_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->kh) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->kw) / d->stride + 1,
                "conv2d: Ho/Wo (%d,%d) do not match H,W,k,stride,pad", d->Ho, d->Wo);
     CC_REQUIRE((long long)d->B * d->H * d->W < (1ll << 31), "conv2d: too many input pixels");
-    ConvP p{};
+    // cases the persistent kernel does not cover go to the generic one: an upsampled operand under a window or padding,
+    // more than 64 taps, byte offsets beyond 32 bits
+    bool generic = d->kh * d->kw > 64;
+    const int es = cc_esize(d->dtype);
+    for (int s = 0; s < d->nseg; ++s) {
+        const ccnet_slice& sl = d->in[s];
+        if (sl.shift > 0 && (d->kh > 1 || d->kw > 1 || d->pad > 0)) generic = true;
+        if ((double)(d->kh * d->W + d->kw) * sl.ldc * es >= 4.0e9) generic = true;
+    }
+    if (generic) return ccnet_conv2d_generic(d, stream);
+
+    ConvQ p{};
     int ctot = 0;
     for (int s = 0; s < d->nseg; ++s) {
         const ccnet_slice& sl = d->in[s];
         CC_REQUIRE(cc_slice_vec_ok(sl, d->dtype), "conv2d: input slice %d is not 16-byte channel aligned (C=%d ldc=%d coff=%d)", s, sl.C, sl.ldc, sl.coff);
         CC_REQUIRE((d->H % (1 << sl.shift)) == 0 && (d->W % (1 << sl.shift)) == 0, "conv2d: H,W not divisible by the upsampling factor");
-        p.seg[s] = SegP{(const unsigned char*)sl.ptr, sl.ldc, sl.coff, sl.C, sl.shift, d->H >> sl.shift, d->W >> sl.shift};
+        p.seg[s] = SegQ{(const unsigned char*)sl.ptr + (size_t)sl.coff * es, (unsigned)(sl.ldc * es), sl.shift, d->H >> sl.shift, d->W >> sl.shift};
         ctot += sl.C;
     }
     if (d->nseg == 1) p.seg[1] = p.seg[0];
+    p.nseg = d->nseg;
     p.Ctot = ctot;
-    p.C0 = d->in[0].C;
+    p.C0 = d->nseg == 2 ? d->in[0].C : ctot;
     int coutp = 0, kpad = 0;
     ccnet_conv_pack_dims(d->dtype, d->Cout, d->kh * d->kw * ctot, &coutp, &kpad);
     CC_REQUIRE(d->weight && ((uintptr_t)d->weight % 16) == 0, "conv2d: weight pointer must be 16-byte aligned");
     CC_REQUIRE(d->Kpad == kpad && d->Cout_pad == coutp, "conv2d: weight packed as [%d][%d], expected [%d][%d]", d->Cout_pad, d->Kpad, coutp, kpad);
-    p.B = d->B; p.H = d->H; p.W = d->W; p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad;
+    p.H = d->H; p.W = d->W; p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad;
     p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
-    p.M = (long long)d->B * d->Ho * d->Wo;
+    const long long M = (long long)d->B * d->Ho * d->Wo;
+    CC_REQUIRE(M > 0 && M < (1ll << 31) - BM, "conv2d: too many output pixels");
+    p.M = (unsigned)M;
+    p.ntiles = (unsigned)((M + BM - 1) / BM);
+    magic_div((unsigned)d->Wo, &p.magicW, &p.shiftW);
+    magic_div((unsigned)d->Ho, &p.magicH, &p.shiftH);
     p.weight = (const unsigned char*)d->weight;
     p.Kpad = kpad;
-    p.nk = kpad / (BKB / cc_esize(d->dtype));
+    p.nk = kpad / (BKB / es);
+    CC_REQUIRE((double)p.ntiles * p.nk < 4.0e9, "conv2d: problem too large");
     p.bias = d->bias;
     p.act = d->act;
     CC_REQUIRE(d->act >= CCNET_ACT_NONE && d->act <= CCNET_ACT_LRELU, "conv2d: unknown activation %d", d->act);
@@ -312,7 +478,7 @@ extern "C" int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream) {
         const ccnet_slice& r = d->residual;
         CC_REQUIRE(r.shift == 0 && r.C == d->Cout && r.coff >= 0 && r.ldc >= r.coff + r.C, "conv2d: bad residual slice");
         p.res_ptr = (const unsigned char*)r.ptr; p.res_ldc = r.ldc; p.res_coff = r.coff;
-        int rg = 16 / cc_esize(d->dtype);
+        int rg = 16 / es;
         vec = vec && (r.ldc % rg) == 0 && (r.coff % rg) == 0 && ((uintptr_t)r.ptr % 16) == 0 && (r.ldc % 8) == 0 && (r.coff % 8) == 0;
     }
     p.vec_out = vec ? 1 : 0;
@@ -323,7 +489,7 @@ extern "C" int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream) {
             if (dt == CCNET_BF16) return odt == CCNET_BF16 ? launch<__bf16, __bf16>(p, bn, st) : launch<__bf16, float>(p, bn, st);
             return launch<float, float>(p, bn, st);
         },
-        stream, CCNET_OP_CONV, 2.0 * (double)p.M * d->Cout * d->kh * d->kw * ctot,
-        ((double)d->B * d->H * d->W * ctot + (double)d->Cout * d->kh * d->kw * ctot) * cc_esize(d->dtype) +
-            (double)p.M * d->Cout * (cc_esize(d->out_dtype) + (d->residual.ptr ? cc_esize(d->dtype) : 0)));
+        stream, CCNET_OP_CONV, 2.0 * (double)M * d->Cout * d->kh * d->kw * ctot,
+        ((double)d->B * d->H * d->W * ctot + (double)d->Cout * d->kh * d->kw * ctot) * es +
+            (double)M * d->Cout * (cc_esize(d->out_dtype) + (d->residual.ptr ? es : 0)));
 }
