@@ -147,6 +147,18 @@ def main():
                 "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2), "flops_per_forward": conv_fl,
                 "forward_ms_sum_of_ops": round(sum(ms), 3)}
     if args.breakdown and rank == 0:
+        def timed(fn, n=5):
+            fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                r = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3, r
+        t_fwd, outs = timed(lambda: net(x))
+        t_dec, dec = timed(lambda: bbox.decode_outputs(outs, [S, S]))
+        t_pp, _ = timed(lambda: bbox.post_process(dec, 6, [S, S], info, args.conf, args.nms))
+        print("phases: forward %.3f ms  decode %.3f ms  post_process %.3f ms" % (t_fwd, t_dec, t_pp), file=sys.stderr)
         names = {0: "other", 1: "conv", 2: "stem", 3: "dwconv", 4: "sppf", 5: "maxpool", 6: "cbam", 7: "eca", 8: "asff", 9: "layernorm",
                  10: "attention"}
         agg = {}

@@ -36,6 +36,7 @@ struct SegQ {
     const unsigned char* ptr;  // first element of the slice (channel offset applied)
     unsigned ldcB;             // pixel stride in bytes
     int shift, Hs, Ws;
+    unsigned span;             // bytes addressable from ptr (< 2^31)
 };
 
 struct ConvQ {
@@ -71,11 +72,15 @@ template <> struct Frag<float> {
     }
 };
 
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BKB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned magic, unsigned shift) { return (__umulhi(n, magic) + n) >> shift; }
 
 #ifndef CC_AB
-#define CC_AB 0  // perf-ablation bit mask (debug builds only): 1 no gather, 2 no stage, 4 no barrier, 8 no LDS reads,
+#define CC_AB 0  // perf-ablation bit mask (debug builds only): 1 no gather, 4 no barrier,
                  // 16 no epilogue, 32 epilogue without stores, 64 stores to a fixed region
 #endif
 
@@ -99,13 +104,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
     const unsigned total = my_tiles * (unsigned)p.nk;
 
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.y * BN;
-    const int lc = t & 7, lr = t >> 3;  // this thread's 16-B chunk column and first row of the staged tiles
-    const bool b_active = (BN >= 32) || (t < BN * 8);
-    const unsigned char* wrow = p.weight + ((size_t)(n0 + (b_active ? lr : 0)) * p.Kpad + lc * EPC) * ES;
+    // Tiles are filled by LDS-DMA (buffer_load_dwordx4 ... lds): one wave instruction writes 1 KB = 8 rows x 128 B of the
+    // tile in lane order, so lane l of wave w owns PHYSICAL slot (l & 7) of rows 8w + (l >> 3) + 32 i and fetches the
+    // LOGICAL chunk that the swizzle puts there (the swizzle goes on the source address).
+    const int lr = t >> 3;
+    const int lc = (t & 7) ^ ((lr >> 1) & 7);
+    const bool b_active = (BN >= 32) || (wave < BN / 8);  // wave-uniform
+
+    // buffer resources: a fetch whose offset is out of range returns zeros, which is how padding taps, rows beyond M
+    // and the zero-padded tail of K are filled -- no select, no exec mask
+    const __amdgpu_buffer_rsrc_t rsrcA0 = make_rsrc(p.seg[0].ptr, p.seg[0].span);
+    const __amdgpu_buffer_rsrc_t rsrcA1 = make_rsrc(p.seg[1].ptr, p.seg[1].span);
+    const __amdgpu_buffer_rsrc_t rsrcB = make_rsrc(p.weight + (size_t)n0 * p.Kpad * ES, (unsigned)BN * (unsigned)p.Kpad * ES);
+    constexpr unsigned OOB = 0x80000000u;  // spans are < 2^31 (checked on the host)
+    unsigned boff[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) boff[i] = (unsigned)((lr + 32 * i) * p.Kpad + lc * EPC) * ES;
 
     // K cursor of this thread's chunk at step 0 of a tile
     int c_init, ky_init, kx_init;
@@ -118,12 +137,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
     }
 
     // ---- gather side state (runs one step ahead of the MFMAs)
-    const unsigned char* rowptr[2][A_LOADS];
+    unsigned rowoff[2][A_LOADS];  // byte offset of tap (0,0), channel 0 of each row in each segment (wraps for negative)
     unsigned long long rmask[A_LOADS];
     unsigned g_tile = tile0;
     int g_k = 0, c = c_init, ky = ky_init, kx = kx_init;
-    u32x4 ra[A_LOADS], rb[B_LOADS];
-    unsigned okbits = 0u;
 
     auto setup_rows = [&](unsigned tile) {
 #pragma unroll
@@ -139,8 +156,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const SegQ& sg = p.seg[s];
-                const long long pix = ((long long)b * sg.Hs + (iy0 >> sg.shift)) * sg.Ws + (ix0 >> sg.shift);
-                rowptr[s][i] = sg.ptr + pix * (long long)sg.ldcB;
+                const int pix = ((int)b * sg.Hs + (iy0 >> sg.shift)) * sg.Ws + (ix0 >> sg.shift);
+                rowoff[s][i] = (unsigned)pix * sg.ldcB;
             }
             unsigned xbits = 0u;
             for (int x = 0; x < p.kw; ++x) xbits |= ((unsigned)(ix0 + x) < (unsigned)p.W ? 1u : 0u) << x;
@@ -150,25 +167,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
             rmask[i] = valid ? mk : 0ull;
         }
     };
-    auto gather = [&]() {
-        const bool s1 = c >= p.C0;  // only possible with two segments (C0 == Ctot otherwise)
+    // issue the LDS-DMA of the (tile, K step) under the gather cursor into buffer `buf`
+    auto gather = [&](int buf) {
+        // the host only sends two-segment problems here when a 128-B window never straddles the segments
+        const bool s1 = __builtin_amdgcn_readfirstlane((int)(c >= p.C0)) != 0;
         const int cs = c - (s1 ? p.C0 : 0);
         const unsigned ldcB = s1 ? p.seg[1].ldcB : p.seg[0].ldcB;
-        const unsigned char* safe = s1 ? p.seg[1].ptr : p.seg[0].ptr;
         const unsigned off = (unsigned)(ky * p.W + kx) * ldcB + (unsigned)cs * ES;
-        const int tap = ky * p.kw + kx;
-        const bool tap_ok = ky < p.kh;  // false in the zero-padded tail of K
-        okbits = 0u;
+        // in the zero-padded tail of K the tap index runs past kh*kw <= 63, where every mask bit is 0
+        const int tap = min(ky * p.kw + kx, 63);
+        const __amdgpu_buffer_rsrc_t rsrcA = s1 ? rsrcA1 : rsrcA0;
+        unsigned char* As = smem + buf * BUF_BYTES + wave * 1024;
+        unsigned char* Bs = As + A_BYTES;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const bool ok = tap_ok && ((rmask[i] >> tap) & 1ull);
-            const unsigned char* ptr = (s1 ? rowptr[1][i] : rowptr[0][i]) + off;
-            ra[i] = *(const u32x4*)(ok ? ptr : safe);
-            okbits |= (ok ? 1u : 0u) << i;
+            const unsigned ok = (unsigned)(rmask[i] >> tap) & 1u;
+            const unsigned v = ok ? (s1 ? rowoff[1][i] : rowoff[0][i]) + off : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(As + i * 4096), 16, (int)v, 0, 0, 0);
         }
-        const size_t koff = (size_t)g_k * BK * ES;
+        if (b_active) {
+            const int koff = g_k * BKB;
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) rb[i] = *(const u32x4*)(wrow + (size_t)(32 * i) * p.Kpad * ES + koff);
+            for (int i = 0; i < B_LOADS; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(Bs + i * 4096), 16, (int)boff[i], koff, 0, 0);
+        }
     };
     // move the gather cursor to the next (tile, K step)
     auto advance = [&]() {
@@ -185,17 +207,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
             }
         }
     };
-    auto stage = [&](int buf) {
-        unsigned char* As = smem + buf * BUF_BYTES;
-        unsigned char* Bs = As + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i)
-            *(u32x4*)(As + lds_off(lr + 32 * i, lc)) = ((okbits >> i) & 1u) ? ra[i] : u32x4{0u, 0u, 0u, 0u};
-        if (b_active) {
-#pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) *(u32x4*)(Bs + lds_off(lr + 32 * i, lc)) = rb[i];
-        }
-    };
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -208,14 +219,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
         const unsigned char* Bs = As + A_BYTES;
         // both halves of the K step are requested up front: the second half's LDS latency hides behind the first MFMAs
         u32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
-#if (CC_AB & 8)
-        // ablation only: MFMAs on whatever the staging registers hold, no LDS traffic
-#pragma unroll
-        for (int i = 0; i < MT; ++i) { fa0[i] = ra[i % A_LOADS]; fa1[i] = ra[(i + 1) % A_LOADS]; }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) { fb0[j] = rb[j % B_LOADS]; fb1[j] = rb[(j + 1) % B_LOADS]; }
-        if (false)
-#endif
         {
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa0[i] = *(const u32x4*)(As + lds_off(wm * WTM + i * 16 + fr, fq));
@@ -321,8 +324,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
     };
 
     setup_rows(g_tile);
-    gather();
-    stage(0);
+    gather(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned c_tile = tile0;  // tile the MFMAs are working on
     int c_k = 0;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
         const bool has_next = (j + 1) < total;
         if (has_next) {
             advance();
-            if (!(CC_AB & 1)) gather();
+            if (!(CC_AB & 1)) gather((int)((j + 1) & 1));  // buffer last read by step j-1, behind that step's barrier
         }
         if (pending) {
             epilogue(pend_tile);
@@ -340,7 +343,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
         }
         if (j == total) break;
         compute((int)(j & 1));
-        if (has_next && !(CC_AB & 2)) stage((int)((j + 1) & 1));
+        // the DMA of step j+1 has had the MFMAs of step j to land; it is ordered for the ds_reads of step j+1 by this
+        // wait in the issuing wave followed by the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(CC_AB & 4)) __syncthreads();
         if (++c_k == p.nk) {
             c_k = 0;
@@ -427,14 +432,21 @@ extern "C" int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream) {
                "conv2d: Ho/Wo (%d,%d) do not match H,W,k,stride,pad", d->Ho, d->Wo);
     CC_REQUIRE((long long)d->B * d->H * d->W < (1ll << 31), "conv2d: too many input pixels");
     // cases the persistent kernel does not cover go to the generic one: an upsampled operand under a window or padding,
-    // more than 64 taps, byte offsets beyond 32 bits
-    bool generic = d->kh * d->kw > 64;
+    // more than 63 taps, byte offsets beyond 32 bits
+    // more than 63 taps, a tensor of 2 GiB or more (32-bit buffer offsets), or two segments whose boundary falls inside
+    // a 128-byte K window (the LDS-DMA picks its segment per window, not per lane)
+    bool generic = d->kh * d->kw > 63;
     const int es = cc_esize(d->dtype);
+    const int bk = BKB / es;
+    double span[2] = {0.0, 0.0};
     for (int s = 0; s < d->nseg; ++s) {
         const ccnet_slice& sl = d->in[s];
+        if (sl.shift < 0 || sl.shift > 3) continue;  // rejected below
         if (sl.shift > 0 && (d->kh > 1 || d->kw > 1 || d->pad > 0)) generic = true;
-        if ((double)(d->kh * d->W + d->kw) * sl.ldc * es >= 4.0e9) generic = true;
+        span[s] = (((double)d->B * (d->H >> sl.shift) * (d->W >> sl.shift) - 1.0) * sl.ldc + sl.C) * es;
+        if (span[s] >= 2147483648.0) generic = true;
     }
+    if (d->nseg == 2 && ((d->in[0].C % bk) != 0 || (d->in[1].C % bk) != 0)) generic = true;
     if (generic) return ccnet_conv2d_generic(d, stream);
 
     ConvQ p{};
@@ -443,7 +455,8 @@ extern "C" int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream) {
         const ccnet_slice& sl = d->in[s];
         CC_REQUIRE(cc_slice_vec_ok(sl, d->dtype), "conv2d: input slice %d is not 16-byte channel aligned (C=%d ldc=%d coff=%d)", s, sl.C, sl.ldc, sl.coff);
         CC_REQUIRE((d->H % (1 << sl.shift)) == 0 && (d->W % (1 << sl.shift)) == 0, "conv2d: H,W not divisible by the upsampling factor");
-        p.seg[s] = SegQ{(const unsigned char*)sl.ptr + (size_t)sl.coff * es, (unsigned)(sl.ldc * es), sl.shift, d->H >> sl.shift, d->W >> sl.shift};
+        p.seg[s] = SegQ{(const unsigned char*)sl.ptr + (size_t)sl.coff * es, (unsigned)(sl.ldc * es), sl.shift, d->H >> sl.shift, d->W >> sl.shift,
+                        (unsigned)span[s]};
         ctot += sl.C;
     }
     if (d->nseg == 1) p.seg[1] = p.seg[0];
@@ -454,6 +467,7 @@ extern "C" int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream) {
     ccnet_conv_pack_dims(d->dtype, d->Cout, d->kh * d->kw * ctot, &coutp, &kpad);
     CC_REQUIRE(d->weight && ((uintptr_t)d->weight % 16) == 0, "conv2d: weight pointer must be 16-byte aligned");
     CC_REQUIRE(d->Kpad == kpad && d->Cout_pad == coutp, "conv2d: weight packed as [%d][%d], expected [%d][%d]", d->Cout_pad, d->Kpad, coutp, kpad);
+    CC_REQUIRE((double)coutp * kpad * es < 2147483648.0, "conv2d: packed weight of 2 GiB or more");
     p.H = d->H; p.W = d->W; p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad;
     p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     const long long M = (long long)d->B * d->Ho * d->Wo;
