@@ -19,6 +19,7 @@
 // (exact fp32, k order permuted identically for A and B).  The weights are the MFMA "A" operand, so each lane ends up
 // with 4 consecutive channels of one pixel per accumulator tile: the epilogue (bias + activation + residual) is
 // register-only and stores 8 B (bf16) / 16 B (fp32) per lane -- an LDS-transposed epilogue cost as much as all MFMAs.
+#include <type_traits>
 #include "common.h"
 
 int ccnet_conv2d_generic(const ccnet_conv_desc* d, ccnet_stream stream);  // conv_generic.hip
@@ -79,10 +80,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BKB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned magic, unsigned shift) { return (__umulhi(n, magic) + n) >> shift; }
 
-#ifndef CC_AB
-#define CC_AB 0  // perf-ablation bit mask (debug builds only): 1 no gather, 4 no barrier,
-                 // 16 no epilogue, 32 epilogue without stores, 64 stores to a fixed region
-#endif
 
 // ACT: activation compiled into the epilogue (CCNET_ACT_*), or ACT_RUNTIME to branch on p.act per element.
 constexpr int ACT_RUNTIME = -1;
@@ -258,60 +255,92 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
             const int n = nbase + j * 16 + r;
             breg[j][r] = (p.bias && n < p.Cout) ? p.bias[n] : 0.0f;
         }
-    auto epilogue = [&](unsigned tile) {
-#if (CC_AB & 16)
+    auto finish4 = [&](int i, int j, float* v) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int r = 0; r < 4; ++r) {
+            const float x = acc[i][j][r] + breg[j][r];
+            if constexpr (ACT == ACT_RUNTIME) v[r] = apply_act(x, p.act);
+            else v[r] = act_fn<ACT>(x);
+        }
+    };
+    auto add_res4 = [&](const unsigned char* rp, float* v) {
+        if constexpr (ES == 2) {
+            const uint2 rv = *(const uint2*)rp;
+            v[0] += bf16_bits_to_f32(rv.x & 0xFFFFu); v[1] += bf16_bits_to_f32(rv.x >> 16);
+            v[2] += bf16_bits_to_f32(rv.y & 0xFFFFu); v[3] += bf16_bits_to_f32(rv.y >> 16);
+        } else {
+            const float4 rv = *(const float4*)rp;
+            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+        }
+    };
+    auto store4 = [&](unsigned char* op, const float* v) {
+        if constexpr (sizeof(OutT) == 2) *(uint2*)op = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        else *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+    };
+    // `full`: every row and channel of the tile exists and the vector path applies -> exactly MT*NT store instructions
+    // per lane, which lets the main loop wait for the DMA issued before them with a counted vmcnt instead of draining
+    // the stores (a drained store costs its whole round trip to L2 once per tile: ruinous for 1-4 K-step problems).
+    auto epilogue = [&](unsigned tile, bool full) {
+        if (full) {
+            const unsigned m0 = tile * BM + wm * WTM + fr;
+            unsigned char* obase = p.out_ptr + ((size_t)m0 * p.out_ldc + p.out_coff + nbase) * sizeof(OutT);
+            const size_t ostep = (size_t)16 * p.out_ldc * sizeof(OutT);
+            if (p.res_ptr) {
+                // all residual loads first, so that they cost one round trip and not MT*NT
+                const unsigned char* rbase = p.res_ptr + ((size_t)m0 * p.res_ldc + p.res_coff + nbase) * ES;
+                const size_t rstep = (size_t)16 * p.res_ldc * ES;
+                using ResV = typename std::conditional<ES == 2, uint2, float4>::type;
+                ResV rv[MT][NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
-        if (false)
-#endif
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const unsigned m = tile * BM + wm * WTM + i * 16 + fr;
-            if (m < p.M) {
-#if (CC_AB & 64)
-                unsigned char* orow = p.out_ptr + ((size_t)(blockIdx.x * BM + wm * WTM + i * 16 + fr) * p.out_ldc + p.out_coff) * sizeof(OutT);
-#else
-                unsigned char* orow = p.out_ptr + ((size_t)m * p.out_ldc + p.out_coff) * sizeof(OutT);
-#endif
-                const unsigned char* rrow = p.res_ptr ? p.res_ptr + ((size_t)m * p.res_ldc + p.res_coff) * ES : nullptr;
+                    for (int j = 0; j < NT; ++j) rv[i][j] = *(const ResV*)(rbase + i * rstep + j * 16 * ES);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int n = nbase + j * 16;
-                    if (n >= p.Cout) continue;
-                    float v[4];
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float x = acc[i][j][r] + breg[j][r];
-                        if constexpr (ACT == ACT_RUNTIME) v[r] = apply_act(x, p.act);
-                        else v[r] = act_fn<ACT>(x);
-                    }
-                    if (p.vec_out && n + 4 <= p.Cout) {
-                        if (rrow) {
-                            if constexpr (ES == 2) {
-                                const uint2 rv = *(const uint2*)(rrow + (size_t)n * 2);
-                                v[0] += bf16_bits_to_f32(rv.x & 0xFFFFu); v[1] += bf16_bits_to_f32(rv.x >> 16);
-                                v[2] += bf16_bits_to_f32(rv.y & 0xFFFFu); v[3] += bf16_bits_to_f32(rv.y >> 16);
-                            } else {
-                                const float4 rv = *(const float4*)(rrow + (size_t)n * 4);
-                                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                            }
-                        }
-#if (CC_AB & 32)
-                        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-                        if (false)
-#endif
-                        if constexpr (sizeof(OutT) == 2) {
-                            *(uint2*)(orow + (size_t)n * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    for (int j = 0; j < NT; ++j) {
+                        float v[4];
+                        finish4(i, j, v);
+                        if constexpr (ES == 2) {
+                            v[0] += bf16_bits_to_f32(rv[i][j].x & 0xFFFFu); v[1] += bf16_bits_to_f32(rv[i][j].x >> 16);
+                            v[2] += bf16_bits_to_f32(rv[i][j].y & 0xFFFFu); v[3] += bf16_bits_to_f32(rv[i][j].y >> 16);
                         } else {
-                            *(float4*)(orow + (size_t)n * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                            v[0] += rv[i][j].x; v[1] += rv[i][j].y; v[2] += rv[i][j].z; v[3] += rv[i][j].w;
                         }
-                    } else {
-                        for (int r = 0; r < 4 && n + r < p.Cout; ++r) {
-                            float x = v[r];
-                            if (rrow) x += load1<T>((const T*)rrow + n + r);
-                            store1<OutT>((OutT*)orow + n + r, x);
+                        store4(obase + i * ostep + j * 16 * sizeof(OutT), v);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        float v[4];
+                        finish4(i, j, v);
+                        store4(obase + i * ostep + j * 16 * sizeof(OutT), v);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const unsigned m = tile * BM + wm * WTM + i * 16 + fr;
+                if (m < p.M) {
+                    unsigned char* orow = p.out_ptr + ((size_t)m * p.out_ldc + p.out_coff) * sizeof(OutT);
+                    const unsigned char* rrow = p.res_ptr ? p.res_ptr + ((size_t)m * p.res_ldc + p.res_coff) * ES : nullptr;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int n = nbase + j * 16;
+                        if (n >= p.Cout) continue;
+                        float v[4];
+                        finish4(i, j, v);
+                        if (p.vec_out && n + 4 <= p.Cout) {
+                            if (rrow) add_res4(rrow + (size_t)n * ES, v);
+                            store4(orow + (size_t)n * sizeof(OutT), v);
+                        } else {
+                            for (int r = 0; r < 4 && n + r < p.Cout; ++r) {
+                                float x = v[r];
+                                if (rrow) x += load1<T>((const T*)rrow + n + r);
+                                store1<OutT>((OutT*)orow + n + r, x);
+                            }
                         }
                     }
                 }
@@ -323,6 +352,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
             for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
+    const bool n_full = p.vec_out && (n0 + BN <= p.Cout);
     setup_rows(g_tile);
     gather(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -335,18 +365,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
         const bool has_next = (j + 1) < total;
         if (has_next) {
             advance();
-            if (!(CC_AB & 1)) gather((int)((j + 1) & 1));  // buffer last read by step j-1, behind that step's barrier
+            gather((int)((j + 1) & 1));  // buffer last read by step j-1, behind that step's barrier
         }
+        bool stores_in_flight = false;
         if (pending) {
-            epilogue(pend_tile);
+            stores_in_flight = n_full && (pend_tile + 1) * BM <= p.M;
+            epilogue(pend_tile, stores_in_flight);
             pending = false;
         }
         if (j == total) break;
         compute((int)(j & 1));
-        // the DMA of step j+1 has had the MFMAs of step j to land; it is ordered for the ds_reads of step j+1 by this
-        // wait in the issuing wave followed by the barrier
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(CC_AB & 4)) __syncthreads();
+        // The DMA of step j+1 has had the MFMAs of step j to land; it is ordered for the ds_reads of step j+1 by this
+        // wait in the issuing wave followed by the barrier.  Vector memory operations retire in order, so with exactly
+        // MT*NT stores issued after the DMA, vmcnt(MT*NT) waits for the DMA only.  Raw s_barrier: __syncthreads()
+        // would add a full vmcnt(0).
+        if (stores_in_flight) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MT * NT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         if (++c_k == p.nk) {
             c_k = 0;
             pending = true;
@@ -395,9 +431,10 @@ int launch_act(const ConvQ& p, hipStream_t st) {
 
 template <typename T, typename OutT, int BN, int WM, int WN>
 int launch_bn(const ConvQ& p, hipStream_t st) {
-    // SiLU (every BaseConv) and identity (prediction / attention / linear layers) get their own code; the rest branch
+    // SiLU (every BaseConv), identity (prediction / attention layers) and ReLU (transformer FFN) get their own code
     if (p.act == CCNET_ACT_SILU) return launch_act<T, OutT, BN, WM, WN, CCNET_ACT_SILU>(p, st);
     if (p.act == CCNET_ACT_NONE) return launch_act<T, OutT, BN, WM, WN, CCNET_ACT_NONE>(p, st);
+    if (p.act == CCNET_ACT_RELU) return launch_act<T, OutT, BN, WM, WN, CCNET_ACT_RELU>(p, st);
     return launch_act<T, OutT, BN, WM, WN, ACT_RUNTIME>(p, st);
 }
 
