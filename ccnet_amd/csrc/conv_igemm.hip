@@ -19,6 +19,7 @@
 // (exact fp32, k order permuted identically for A and B).  The weights are the MFMA "A" operand, so each lane ends up
 // with 4 consecutive channels of one pixel per accumulator tile: the epilogue (bias + activation + residual) is
 // register-only and stores 8 B (bf16) / 16 B (fp32) per lane -- an LDS-transposed epilogue cost as much as all MFMAs.
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 
@@ -26,9 +27,7 @@ int ccnet_conv2d_generic(const ccnet_conv_desc* d, ccnet_stream stream);  // con
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BKB = 128;  // bytes of K per row per step
-constexpr int NTHREADS = 256;
 
 // native vector type for everything staged through registers (arrays of HIP's uint4 struct end up in scratch/LDS)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -84,16 +83,23 @@ __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned magic, unsigned
 // ACT: activation compiled into the epilogue (CCNET_ACT_*), or ACT_RUNTIME to branch on p.act per element.
 constexpr int ACT_RUNTIME = -1;
 
-template <typename T, typename OutT, int BN, int WM, int WN, int ACT>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) {
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n) : "memory")
+
+// Tile BM x BN, WM x WN waves of 64 lanes, NST LDS stages (the DMA runs NST-1 K steps ahead of the MFMAs).
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NST, int ACT>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvQ p) {
+    constexpr int NTHREADS = WM * WN * 64;
     constexpr int ES = (int)sizeof(T);
     constexpr int EPC = 16 / ES;  // elements per 16-B chunk
     constexpr int BK = BKB / ES;  // elements of K per step
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
-    constexpr int A_LOADS = BM / 32;
-    constexpr int B_LOADS = (BN >= 32) ? BN / 32 : 1;
+    constexpr int RPI = NTHREADS / 8;  // tile rows covered by one DMA instruction of the whole block
+    constexpr int A_LOADS = BM / RPI;
+    constexpr int B_LOADS = (BN >= RPI) ? BN / RPI : 1;
     constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB, BUF_BYTES = A_BYTES + B_BYTES;
-    __shared__ __align__(16) unsigned char smem[2 * BUF_BYTES];
+    static_assert(NST == 2 || BN >= RPI, "deep pipelines count DMA instructions per wave: every wave must load B");
+    static_assert(A_LOADS + B_LOADS + 2 * MT * NT < 64, "vmcnt is a 6-bit counter");
+    __shared__ __align__(16) unsigned char smem[NST * BUF_BYTES];
 
     const unsigned tile0 = blockIdx.x, tstride = gridDim.x;
     if (tile0 >= p.ntiles) return;
@@ -107,8 +113,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
     const int fr = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.y * BN;
     // Tiles are filled by LDS-DMA (buffer_load_dwordx4 ... lds): one wave instruction writes 1 KB = 8 rows x 128 B of the
-    // tile in lane order, so lane l of wave w owns PHYSICAL slot (l & 7) of rows 8w + (l >> 3) + 32 i and fetches the
-    // LOGICAL chunk that the swizzle puts there (the swizzle goes on the source address).
+    // tile in lane order, so lane l of wave w owns PHYSICAL slot (l & 7) of rows 8w + (l >> 3) + RPI i and fetches the
+    // LOGICAL chunk that the swizzle puts there (the swizzle goes on the source address); RPI is a multiple of 16, so
+    // the swizzle term is the same for all of a thread's rows.
     const int lr = t >> 3;
     const int lc = (t & 7) ^ ((lr >> 1) & 7);
     const bool b_active = (BN >= 32) || (wave < BN / 8);  // wave-uniform
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
     constexpr unsigned OOB = 0x80000000u;  // spans are < 2^31 (checked on the host)
     unsigned boff[B_LOADS];
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) boff[i] = (unsigned)((lr + 32 * i) * p.Kpad + lc * EPC) * ES;
+    for (int i = 0; i < B_LOADS; ++i) boff[i] = (unsigned)((lr + RPI * i) * p.Kpad + lc * EPC) * ES;
 
     // K cursor of this thread's chunk at step 0 of a tile
     int c_init, ky_init, kx_init;
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
     auto setup_rows = [&](unsigned tile) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const unsigned m = tile * BM + lr + 32 * i;
+            const unsigned m = tile * BM + lr + RPI * i;
             const bool valid = m < p.M;
             const unsigned mm = valid ? m : 0u;
             const unsigned q1 = fastdiv(mm, p.magicW, p.shiftW);
@@ -180,13 +187,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
         for (int i = 0; i < A_LOADS; ++i) {
             const unsigned ok = (unsigned)(rmask[i] >> tap) & 1u;
             const unsigned v = ok ? (s1 ? rowoff[1][i] : rowoff[0][i]) + off : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(As + i * 4096), 16, (int)v, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(As + i * RPI * BKB), 16, (int)v, 0, 0, 0);
         }
         if (b_active) {
             const int koff = g_k * BKB;
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(Bs + i * 4096), 16, (int)boff[i], koff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(Bs + i * RPI * BKB), 16, (int)boff[i], koff, 0, 0);
         }
     };
     // move the gather cursor to the next (tile, K step)
@@ -353,34 +360,69 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const ConvQ p) 
     };
 
     const bool n_full = p.vec_out && (n0 + BN <= p.Cout);
+    constexpr int L = A_LOADS + B_LOADS;  // DMA instructions per wave and K step
+    constexpr int S = MT * NT;            // store instructions per lane of a full tile's epilogue
+
+    // prologue: the first NST-1 steps are put in flight, the first one is awaited
     setup_rows(g_tile);
     gather(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    unsigned issued = 1;  // K steps whose DMA has been issued
+    if (NST == 3 && total > 1) {
+        advance();
+        gather(1);
+        issued = 2;
+        WAIT_VM(L);
+    } else {
+        WAIT_VM(0);
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
     unsigned c_tile = tile0;  // tile the MFMAs are working on
     int c_k = 0;
     bool pending = false;
     unsigned pend_tile = 0;
+    int stores_prev = 0;  // 1: the previous trip issued exactly S stores; 0: none; -1: an uncounted number
     for (unsigned j = 0;; ++j) {  // one extra trip drains the last tile's epilogue (single inlined epilogue body)
-        const bool has_next = (j + 1) < total;
-        if (has_next) {
+        // step j + NST - 1 goes into the buffer that step j - 1 read, behind that step's barrier
+        bool dma_now = false;
+        if (issued < total) {
             advance();
-            gather((int)((j + 1) & 1));  // buffer last read by step j-1, behind that step's barrier
+            gather((int)(issued % NST));
+            ++issued;
+            dma_now = true;
         }
-        bool stores_in_flight = false;
+        int stores_now = 0;
         if (pending) {
-            stores_in_flight = n_full && (pend_tile + 1) * BM <= p.M;
-            epilogue(pend_tile, stores_in_flight);
+            const bool full = n_full && (pend_tile + 1) * BM <= p.M;
+            epilogue(pend_tile, full);
+            stores_now = full ? 1 : -1;
             pending = false;
         }
         if (j == total) break;
-        compute((int)(j & 1));
-        // The DMA of step j+1 has had the MFMAs of step j to land; it is ordered for the ds_reads of step j+1 by this
-        // wait in the issuing wave followed by the barrier.  Vector memory operations retire in order, so with exactly
-        // MT*NT stores issued after the DMA, vmcnt(MT*NT) waits for the DMA only.  Raw s_barrier: __syncthreads()
-        // would add a full vmcnt(0).
-        if (stores_in_flight) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MT * NT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        compute((int)(j % NST));
+        // Step j+1 must have landed before the barrier that lets every wave read it.  Vector memory operations retire
+        // in order, so it is enough to allow as many outstanding operations as were issued AFTER its DMA: with two
+        // stages that is this trip's stores; with three, also the previous trip's stores and this trip's DMA.
+        // Raw s_barrier: __syncthreads() would add a full vmcnt(0).
+        if (NST == 2) {
+            if (stores_now == 1) WAIT_VM(S);
+            else WAIT_VM(0);
+        } else {
+            const bool counted = stores_now >= 0 && stores_prev >= 0;
+            const int ns = stores_now + stores_prev;
+            if (!counted) WAIT_VM(0);
+            else if (dma_now) {
+                if (ns == 0) WAIT_VM(L);
+                else if (ns == 1) WAIT_VM(L + S);
+                else WAIT_VM(L + 2 * S);
+            } else {
+                if (ns == 0) WAIT_VM(0);
+                else if (ns == 1) WAIT_VM(S);
+                else WAIT_VM(2 * S);
+            }
+        }
+        stores_prev = stores_now;
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (++c_k == p.nk) {
@@ -401,51 +443,67 @@ void magic_div(unsigned d, unsigned* magic, unsigned* shift) {
     *magic = (unsigned)((((1ull << s) - d) << 32) / d + 1);
 }
 
-template <typename T, typename OutT, int BN, int WM, int WN, int ACT>
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NST, int ACT>
 int resident_blocks() {
-    auto kernel = conv_igemm_kernel<T, OutT, BN, WM, WN, ACT>;
+    auto kernel = conv_igemm_kernel<T, OutT, BM, BN, WM, WN, NST, ACT>;
     // blocks of this instantiation that fit on the chip at once (cached per instantiation and device)
     static int cached[16] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
     if (cached[dev] == 0) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, NTHREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, WM * WN * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         cached[dev] = per_cu * cus;
     }
     return cached[dev];
 }
 
-template <typename T, typename OutT, int BN, int WM, int WN, int ACT>
-int launch_act(const ConvQ& p, hipStream_t st) {
-    auto kernel = conv_igemm_kernel<T, OutT, BN, WM, WN, ACT>;
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NST, int ACT>
+int launch_act(ConvQ p, hipStream_t st) {
+    auto kernel = conv_igemm_kernel<T, OutT, BM, BN, WM, WN, NST, ACT>;
+    p.ntiles = (p.M + BM - 1) / BM;
     const int gy = (p.Cout + BN - 1) / BN;
-    int gx = resident_blocks<T, OutT, BN, WM, WN, ACT>() / gy;
+    int gx = resident_blocks<T, OutT, BM, BN, WM, WN, NST, ACT>() / gy;
     if (gx < 1) gx = 1;
     if ((unsigned)gx > p.ntiles) gx = (int)p.ntiles;
-    hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(NTHREADS), 0, st, p);
+    hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(WM * WN * 64), 0, st, p);
     CC_LAUNCH_CHECK();
     return CCNET_OK;
 }
 
-template <typename T, typename OutT, int BN, int WM, int WN>
-int launch_bn(const ConvQ& p, hipStream_t st) {
+template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NST>
+int launch_tile(const ConvQ& p, hipStream_t st) {
     // SiLU (every BaseConv), identity (prediction / attention layers) and ReLU (transformer FFN) get their own code
-    if (p.act == CCNET_ACT_SILU) return launch_act<T, OutT, BN, WM, WN, CCNET_ACT_SILU>(p, st);
-    if (p.act == CCNET_ACT_NONE) return launch_act<T, OutT, BN, WM, WN, CCNET_ACT_NONE>(p, st);
-    if (p.act == CCNET_ACT_RELU) return launch_act<T, OutT, BN, WM, WN, CCNET_ACT_RELU>(p, st);
-    return launch_act<T, OutT, BN, WM, WN, ACT_RUNTIME>(p, st);
+    if (p.act == CCNET_ACT_SILU) return launch_act<T, OutT, BM, BN, WM, WN, NST, CCNET_ACT_SILU>(p, st);
+    if (p.act == CCNET_ACT_NONE) return launch_act<T, OutT, BM, BN, WM, WN, NST, CCNET_ACT_NONE>(p, st);
+    if (p.act == CCNET_ACT_RELU) return launch_act<T, OutT, BM, BN, WM, WN, NST, CCNET_ACT_RELU>(p, st);
+    return launch_act<T, OutT, BM, BN, WM, WN, NST, ACT_RUNTIME>(p, st);
 }
 
+// big: 256-row tiles, 8 waves, one block per CU with a three-stage ring (two K steps of DMA in flight); chosen when the
+// problem has enough of them to fill the chip a few times over.  Otherwise 128-row tiles, 4 waves, two blocks per CU.
 template <typename T, typename OutT>
-int launch(const ConvQ& p, int bn, hipStream_t st) {
-    switch (bn) {
-        case 128: return launch_bn<T, OutT, 128, 2, 2>(p, st);
-        case 64: return launch_bn<T, OutT, 64, 2, 2>(p, st);
-        case 32: return launch_bn<T, OutT, 32, 4, 1>(p, st);
-        default: return launch_bn<T, OutT, 16, 4, 1>(p, st);
+int launch(const ConvQ& p, int bn, bool big, hipStream_t st) {
+    if (big) {
+        if (bn == 128) return launch_tile<T, OutT, 256, 128, 4, 2, 3>(p, st);
+        return launch_tile<T, OutT, 256, 64, 4, 2, 3>(p, st);
     }
+    switch (bn) {
+        case 128: return launch_tile<T, OutT, 128, 128, 2, 2, 2>(p, st);
+        case 64: return launch_tile<T, OutT, 128, 64, 2, 2, 2>(p, st);
+        case 32: return launch_tile<T, OutT, 128, 32, 4, 1, 2>(p, st);
+        default: return launch_tile<T, OutT, 128, 16, 4, 1, 2>(p, st);
+    }
+}
+
+int conv_big_policy() {  // CCNET_CONV_BIG=0/1 forces the tile choice (tuning aid); unset = automatic
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("CCNET_CONV_BIG");
+        v = e ? atoi(e) : -1;
+    }
+    return v;
 }
 
 }  // namespace
@@ -508,15 +566,14 @@ extern "C" int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream) {
     p.H = d->H; p.W = d->W; p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad;
     p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     const long long M = (long long)d->B * d->Ho * d->Wo;
-    CC_REQUIRE(M > 0 && M < (1ll << 31) - BM, "conv2d: too many output pixels");
+    CC_REQUIRE(M > 0 && M < (1ll << 31) - 256, "conv2d: too many output pixels");
     p.M = (unsigned)M;
-    p.ntiles = (unsigned)((M + BM - 1) / BM);
     magic_div((unsigned)d->Wo, &p.magicW, &p.shiftW);
     magic_div((unsigned)d->Ho, &p.magicH, &p.shiftH);
     p.weight = (const unsigned char*)d->weight;
     p.Kpad = kpad;
     p.nk = kpad / (BKB / es);
-    CC_REQUIRE((double)p.ntiles * p.nk < 4.0e9, "conv2d: problem too large");
+    CC_REQUIRE((double)M / 128 * p.nk < 4.0e9, "conv2d: problem too large");
     p.bias = d->bias;
     p.act = d->act;
     CC_REQUIRE(d->act >= CCNET_ACT_NONE && d->act <= CCNET_ACT_LRELU, "conv2d: unknown activation %d", d->act);
@@ -535,10 +592,13 @@ extern "C" int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream) {
     p.vec_out = vec ? 1 : 0;
     const int bn = pick_bn(d->Cout);
     const int dt = d->dtype, odt = d->out_dtype;
+    const long long tiles256 = ((M + 255) / 256) * ((d->Cout + bn - 1) / bn);
+    (void)tiles256;  // the 256-row / 3-stage variant measures slower than two 128-row blocks per CU so far: opt-in only
+    const bool big = bn >= 64 && conv_big_policy() == 1;
     return ccnet_submit(
-        [p, bn, dt, odt](hipStream_t st, const float*) -> int {
-            if (dt == CCNET_BF16) return odt == CCNET_BF16 ? launch<__bf16, __bf16>(p, bn, st) : launch<__bf16, float>(p, bn, st);
-            return launch<float, float>(p, bn, st);
+        [p, bn, big, dt, odt](hipStream_t st, const float*) -> int {
+            if (dt == CCNET_BF16) return odt == CCNET_BF16 ? launch<__bf16, __bf16>(p, bn, big, st) : launch<__bf16, float>(p, bn, big, st);
+            return launch<float, float>(p, bn, big, st);
         },
         stream, CCNET_OP_CONV, 2.0 * (double)M * d->Cout * d->kh * d->kw * ctot,
         ((double)d->B * d->H * d->W * ctot + (double)d->Cout * d->kh * d->kw * ctot) * es +
