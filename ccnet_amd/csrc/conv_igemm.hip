@@ -183,12 +183,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvQ
         const __amdgpu_buffer_rsrc_t rsrcA = s1 ? rsrcA1 : rsrcA0;
         unsigned char* As = smem + buf * BUF_BYTES + wave * 1024;
         unsigned char* Bs = As + A_BYTES;
+#ifdef CC_EXP
+        if (!((CC_EXP & 1) && __builtin_amdgcn_readfirstlane(tap) != 0))
+#endif
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const unsigned ok = (unsigned)(rmask[i] >> tap) & 1u;
             const unsigned v = ok ? (s1 ? rowoff[1][i] : rowoff[0][i]) + off : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(As + i * RPI * BKB), 16, (int)v, 0, 0, 0);
         }
+#ifdef CC_EXP
+        if (!((CC_EXP & 2) && g_k != 0))
+#endif
         if (b_active) {
             const int koff = g_k * BKB;
 #pragma unroll

@@ -268,3 +268,34 @@ def test_all_gather_detections_world2_gloo():
         assert len(got) == 4
         for a, b in zip(got, e):
             assert (a is None and b is None) or (a.shape == b.shape and np.array_equal(a, b))
+
+
+# ------------------------------------------------------------------------------------------ mAP restatement
+def test_map_restatement_matches_reference_get_map():
+    """ccnet_amd/utils/map.py against golden values produced by the reference's own get_map / voc_ap
+    (oracle/make_golden_map.py): three synthetic datasets x ten IoU thresholds, and six raw precision/recall curves."""
+    import json
+    from ccnet_amd.utils import map as cmap
+    with open(os.path.join(GOLD, "map_case.json")) as f:
+        gold = json.load(f)
+    for case in gold["get_map"]:
+        gt = [[tuple(g) for g in img] for img in case["gt"]]
+        dets = [[(d[0], float(str(d[1])[:6]), d[2], d[3], d[4], d[5]) for d in img] for img in case["dets"]]
+        for thr, ref in zip(case["thresholds"], case["map"]):
+            got, _ = cmap.average_precision(gt, dets, case["num_classes"], thr)
+            assert abs(got - ref) < 1e-12, (case["seed"], thr, got, ref)
+        m, vals = cmap.map_50_95(gt, dets, case["num_classes"])
+        assert abs(m - float(np.mean(case["map"]))) < 1e-12
+    for c in gold["voc_ap"]:
+        assert abs(cmap.voc_ap(c["rec"], c["prec"]) - c["ap"]) < 1e-12
+
+
+def test_map_records_follow_eval_txt_format():
+    """tools/eval.py:89-103: score = obj*cls, str()[:6]; pixels truncated with int(); columns top,left,bottom,right."""
+    from ccnet_amd.utils import map as cmap
+    out = [np.array([[10.9, 20.2, 30.7, 40.99, 0.9, 0.87654321, 2.0]], dtype=np.float32), np.zeros((0, 7), np.float32), None]
+    recs = cmap.detections_to_records(out)
+    assert recs[1] == [] and recs[2] == []
+    c, conf, l, t, r, b = recs[0][0]
+    assert (c, l, t, r, b) == (2, 20, 10, 40, 30)
+    assert conf == float(str(np.float32(0.9) * np.float32(0.87654321))[:6])
