@@ -160,6 +160,17 @@ def main():
                 "all_conv_launches": {"n": len(conv), "ms_per_forward": round(conv_ms, 3),
                                       "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else 0.0},
                 "forward_ms_sum_of_ops": round(sum(ms), 3)}
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes over this same command (scripts/profile_bench.sh,
+    # scripts/traffic_from_pmc.py); the newest committed summary is attached, null if there is none
+    import glob
+    tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_conv_traffic.json")))
+    if tf and args.kind == "net" and args.precision == "bf16" and B == 64 and S == 640:
+        with open(tf[-1]) as f:
+            tj = json.load(f)
+        roofline["traffic"] = round(tj["hot"]["hbm_bytes_per_launch"])
+        roofline["traffic_note"] = "%s: HBM-side bytes per MFMA-bound launch (%s); algorithmic bytes per launch %d" % (
+            os.path.basename(tf[-1]), tj["correction"], round(tj["hot"]["algorithmic_bytes_per_launch"]))
+        roofline["hbm_bound_launches"]["traffic"] = round(tj["thin"]["hbm_bytes_per_launch"])
     if args.breakdown and rank == 0:
         def timed(fn, n=5):
             fn()

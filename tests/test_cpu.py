@@ -299,3 +299,15 @@ def test_map_records_follow_eval_txt_format():
     c, conf, l, t, r, b = recs[0][0]
     assert (c, l, t, r, b) == (2, 20, 10, 40, 30)
     assert conf == float(str(np.float32(0.9) * np.float32(0.87654321))[:6])
+
+
+def test_socket_inference_surface(tmp_path):
+    """tools/socket2springboot.py:33-123: unknown model names give {}, classes.txt is one name per line."""
+    from ccnet_amd.tools import socket2springboot as s2s
+    assert s2s.inference("Other", "x.pth", "NEUDET", [224, 224], 0.5, 0.6, ["a.jpg"]) == {}
+    p = tmp_path / "classes.txt"
+    p.write_text("crazing\ninclusion\n\npatches\n")
+    assert s2s.get_classes(str(p)) == (["crazing", "inclusion", "patches"], 3)
+    import inspect
+    assert list(inspect.signature(s2s.inference).parameters)[:7] == ["model_name", "model_path", "dataset", "input_shape", "conf_thres",
+                                                                      "nms_thres", "image_paths"]
