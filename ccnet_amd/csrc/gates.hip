@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int POOL_CHUNK = 1024;  // pixels per partial block
+constexpr int POOL_CHUNK = 128;  // pixels per partial block (small: a 20x20 map must still spread over the chip)
 
 // scratch layout (floats): partial[B][nchunk][2][C] | ca[B][C] | stats[B][H*W][2]
 struct GateScratch {
@@ -99,7 +99,16 @@ __global__ __launch_bounds__(256) void cbam_mlp_kernel(const float* partial, int
     for (int c = t; c < C; c += 256) {
         const float* wr = fc2 + (size_t)c * Cr;
         float a = 0.0f, m = 0.0f;
-        for (int j = 0; j < Cr; ++j) { a = fmaf(wr[j], hid[j], a); m = fmaf(wr[j], hid[Cr + j], m); }
+        if ((Cr & 3) == 0) {  // rows of fc2 are 16-byte aligned then
+#pragma unroll 4
+            for (int j = 0; j < Cr; j += 4) {
+                const float4 w4 = *(const float4*)(wr + j);
+                a = fmaf(w4.x, hid[j], a); a = fmaf(w4.y, hid[j + 1], a); a = fmaf(w4.z, hid[j + 2], a); a = fmaf(w4.w, hid[j + 3], a);
+                m = fmaf(w4.x, hid[Cr + j], m); m = fmaf(w4.y, hid[Cr + j + 1], m); m = fmaf(w4.z, hid[Cr + j + 2], m); m = fmaf(w4.w, hid[Cr + j + 3], m);
+            }
+        } else {
+            for (int j = 0; j < Cr; ++j) { a = fmaf(wr[j], hid[j], a); m = fmaf(wr[j], hid[Cr + j], m); }
+        }
         ca[(size_t)b * C + c] = sigmoidf_(a + m);
     }
 }
