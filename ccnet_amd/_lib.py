@@ -51,6 +51,8 @@ def lib():
         L.ccnet_asff_fuse.argtypes = [Slice, Slice, Slice, Slice, i32, i32, i32, i32, Slice, vp]
         L.ccnet_layernorm.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, f32, vp]
         L.ccnet_attention.argtypes = [Slice, Slice, Slice, i32, i32, i32, i32, i32, i32, Slice, vp]
+        L.ccnet_transformer_fused_frags.argtypes = [i32, i32, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        L.ccnet_transformer_fused.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, C.c_longlong, vp, i32, i32, vp]
         L.ccnet_decode.argtypes = [C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32),
                                    i32, i32, i32, f32, f32, vp, vp]
         L.ccnet_filter.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp]

@@ -16,6 +16,7 @@ Fusions relative to the reference (all exact in real arithmetic):
   - residual adds (Bottleneck, Transformer) happen in the producing GEMM's epilogue.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -361,6 +362,17 @@ class Compiler:
 
     def transformer(self, p, src, rows, N, nhead=2, n_enc=6, n_dec=6):
         """nn.Transformer(src, src) in eval mode: post-norm, ReLU (model_block.py:270-271, 290)."""
+        S = rows // N
+        ff = self.sd[p + ".encoder.layers.0.linear1.weight"].shape[0] if n_enc else 0
+        if (self.dtype == BF16 and src.C == 256 and nhead == 2 and ff == 1024 and S <= 64 and src.coff == 0
+                and os.environ.get("CCNET_NO_FUSED_TRANSFORMER", "0") == "0"):
+            # the whole stack in one launch (one workgroup per spatial position, transformer_fused.hip)
+            wst, pvec, fpw = ops.pack_transformer(self.sd, p, n_enc, n_dec, self.dev)
+            self.keep.extend([wst, pvec])
+            out = torch.empty(rows, src.C, dtype=self.tdt, device=self.dev)
+            self.keep.append(out)
+            ops.transformer_fused(src.buf, src.buf.shape[-1], out, src.C, S, N, wst, fpw, pvec, n_enc, n_dec)
+            return T(out, 0, src.C, 1, rows)
         x = src
         for i in range(n_enc):
             q = "%s.encoder.layers.%d" % (p, i)

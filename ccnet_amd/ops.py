@@ -134,6 +134,94 @@ def attention(q, k, v, dtype, Sq, Sk, N, heads, hd, out):
     check(lib().ccnet_attention(q, k, v, dtype, Sq, Sk, N, heads, hd, out, stream_ptr()))
 
 
+def _mfma_frags(w):
+    """(N, K) matrix -> [N/16][K/32][512] fragments: the 64-lane A operand of v_mfma_f32_16x16x32_bf16
+    (lane l holds row l & 15, k = (l >> 4) * 8 .. + 7)."""
+    n, k = w.shape
+    return w.reshape(n // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(n // 16, k // 32, 512)
+
+
+def pack_transformer(sd, prefix, n_enc, n_dec, device):
+    """Weight stream and parameter vector of ccnet_transformer_fused for the nn.Transformer under `prefix`
+    (d_model 256, 2 heads, FF 1024).  The order below IS the kernel's program order (transformer_fused.hip), for each of
+    its 8 waves: per attention block, per head, Q/K/V projections (wave w owns 16 columns of each), then out_proj (wave w
+    owns 32 columns); per FFN, four 256-wide hidden chunks, linear1 chunk then the matching K slice of linear2.
+    Inside a GEMM call fragments run k-tile major, n-tile minor."""
+    E, FF, NW, RING = 256, 1024, 8, 16
+    f64 = lambda t: t.detach().to(torch.float64).cpu()
+
+    def attn(q):
+        fin = _mfma_frags(f64(sd[q + ".in_proj_weight"]))
+        fout = _mfma_frags(f64(sd[q + ".out_proj.weight"]))
+        per_wave = []
+        for w in range(NW):
+            seq = []
+            for h in range(2):
+                for part in range(3):
+                    nt = (part * E + h * 128 + w * 16) // 16
+                    for kt in range(8):
+                        seq.append(fin[nt, kt])
+            for kt in range(8):
+                for j in range(2):
+                    seq.append(fout[w * 2 + j, kt])
+            per_wave.append(torch.stack(seq))
+        return per_wave, [f64(sd[q + ".in_proj_bias"]), f64(sd[q + ".out_proj.bias"])]
+
+    def ffn(q):
+        f1 = _mfma_frags(f64(sd[q + ".linear1.weight"]))
+        f2 = _mfma_frags(f64(sd[q + ".linear2.weight"]))
+        per_wave = []
+        for w in range(NW):
+            seq = []
+            for c in range(FF // 256):
+                for kt in range(8):
+                    for j in range(2):
+                        seq.append(f1[c * 16 + w * 2 + j, kt])
+                for kt in range(8):
+                    for j in range(2):
+                        seq.append(f2[w * 2 + j, c * 8 + kt])
+            per_wave.append(torch.stack(seq))
+        return per_wave, [f64(sd[q + ".linear1.bias"]), f64(sd[q + ".linear2.bias"])]
+
+    def ln(q):
+        return [f64(sd[q + ".weight"]), f64(sd[q + ".bias"])]
+
+    streams = [[] for _ in range(NW)]
+    params = []
+
+    def emit(block):
+        pw, pr = block
+        for w in range(NW):
+            streams[w].append(pw[w])
+        params.extend(pr)
+
+    for i in range(n_enc):
+        q = "%s.encoder.layers.%d" % (prefix, i)
+        emit(attn(q + ".self_attn")); params.extend(ln(q + ".norm1"))
+        emit(ffn(q)); params.extend(ln(q + ".norm2"))
+    params.extend(ln(prefix + ".encoder.norm"))
+    for i in range(n_dec):
+        q = "%s.decoder.layers.%d" % (prefix, i)
+        emit(attn(q + ".self_attn")); params.extend(ln(q + ".norm1"))
+        emit(attn(q + ".multihead_attn")); params.extend(ln(q + ".norm2"))
+        emit(ffn(q)); params.extend(ln(q + ".norm3"))
+    params.extend(ln(prefix + ".decoder.norm"))
+    fpw, npar = C.c_longlong(), C.c_longlong()
+    check(lib().ccnet_transformer_fused_frags(n_enc, n_dec, C.byref(fpw), C.byref(npar)))
+    per_wave = [torch.cat(s) if s else torch.zeros(0, 512, dtype=torch.float64) for s in streams]
+    assert all(pw.shape[0] == fpw.value for pw in per_wave), (per_wave[0].shape, fpw.value)
+    pad = torch.zeros(RING, 512, dtype=torch.float64)  # the ring prefetches RING fragments past the end
+    stream = torch.stack([torch.cat([pw, pad]) for pw in per_wave]).to(torch.bfloat16).contiguous().to(device)
+    pvec = torch.cat([t.reshape(-1) for t in params]).to(torch.float32).contiguous().to(device)
+    assert pvec.numel() == npar.value, (pvec.numel(), npar.value)
+    return stream, pvec, fpw.value
+
+
+def transformer_fused(src, src_ld, out, out_ld, S, N, stream_w, fpw, params, n_enc, n_dec):
+    check(lib().ccnet_transformer_fused(src.data_ptr(), src_ld, out.data_ptr(), out_ld, S, N, 256, 2, 1024, stream_w.data_ptr(), fpw,
+                                        params.data_ptr(), n_enc, n_dec, stream_ptr()))
+
+
 def decode(heads, nc, in_h, in_w, out):
     """heads: list of fp32 CUDA tensors viewed as (B, 5+nc, h, w) with arbitrary strides over (b, c) and a uniform
     pixel stride (NCHW contiguous or an NHWC buffer permuted to NCHW)."""

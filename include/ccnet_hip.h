@@ -122,6 +122,20 @@ int ccnet_layernorm(const void* x, const void* res, const float* gamma, const fl
 int ccnet_attention(ccnet_slice q, ccnet_slice k, ccnet_slice v, int dtype, int Sq, int Sk, int N, int heads, int hd,
                     ccnet_slice out, ccnet_stream stream);
 
+/* The whole torch.nn.Transformer(src, src) of MobileViT (network/model_block.py:270-271, 290; torch's
+ * nn/modules/transformer.py encoder/decoder stacks, post-norm, ReLU, eval mode) in one launch, bf16 only.
+ * With batch_first=False the sequence axis is the image batch, so the stack is N independent problems of S tokens:
+ * one workgroup per spatial position keeps its tokens in LDS through all layers and streams the weights.
+ * src/out: rows (s*N + n) of d_model bf16, row strides src_ld/out_ld elements.  Built for d_model 256, 2 heads,
+ * dim_ff 1024, 1 <= S <= 64 (anything else: CCNET_EINVAL; callers fall back to the per-op entry points above).
+ * wstream: bf16 MFMA fragments in per-wave consumption order, [8][frags_per_wave + 16][64][8]; params: fp32 biases and
+ * LayerNorm gamma/beta in program order (layout: ccnet_amd/ops.py:pack_transformer, transformer_fused.hip).
+ * ccnet_transformer_fused_frags reports the stream lengths for a given depth. */
+int ccnet_transformer_fused_frags(int n_enc, int n_dec, long long* frags_per_wave, long long* param_floats);
+int ccnet_transformer_fused(const void* src, int src_ld, void* out, int out_ld, int S, int N, int d_model, int nhead,
+                            int dim_ff, const void* wstream, long long frags_per_wave, const float* params, int n_enc,
+                            int n_dec, ccnet_stream stream);
+
 /* ---- decode + post-process --------------------------------------------------------------------------------
  * decode_outputs (utils/bbox.py:13-79).  heads: nlev raw fp32 maps, element (b,c,y,x) of level l at
  * head_dev[l][b*sb[l] + c*sc[l] + (y*w[l]+x)*sp[l]].  out_dev: fp32 [B][A][5+nc] contiguous.
@@ -161,7 +175,7 @@ void ccnet_plan_destroy(ccnet_plan* plan);
 enum {
     CCNET_OP_OTHER = 0, CCNET_OP_CONV = 1, CCNET_OP_STEM = 2, CCNET_OP_DWCONV = 3, CCNET_OP_SPPF = 4, CCNET_OP_MAXPOOL = 5,
     CCNET_OP_CBAM = 6, CCNET_OP_ECA = 7, CCNET_OP_ASFF = 8, CCNET_OP_LAYERNORM = 9, CCNET_OP_ATTENTION = 10,
-    CCNET_OP_DECODE = 11, CCNET_OP_FILTER = 12, CCNET_OP_NMS = 13
+    CCNET_OP_DECODE = 11, CCNET_OP_FILTER = 12, CCNET_OP_NMS = 13, CCNET_OP_TRANSFORMER = 14
 };
 int ccnet_plan_op_info(const ccnet_plan* plan, int i, int* kind, double* flops, double* bytes);
 int ccnet_plan_run_timed(const ccnet_plan* plan, const float* x_dev, ccnet_stream stream, float* ms_per_op);
