@@ -409,3 +409,42 @@ def test_nms_heavy_bit_exact():
         nb = counts[b]
         ref = orc.batched_nms_reference(cand[b, :nb, :4], cand[b, :nb, 4] * cand[b, :nb, 5], cand[b, :nb, 6], 0.6)
         assert np.array_equal(np.asarray(keep[b], np.int64), ref)
+
+
+# ------------------------------------------------------------------------------------------ fused transformer
+@pytest.mark.parametrize("S,N,n_enc,n_dec", [(64, 6, 2, 2), (5, 3, 1, 2), (1, 7, 1, 1), (33, 4, 6, 6)])
+def test_transformer_fused_matches_torch(S, N, n_enc, n_dec):
+    """ccnet_transformer_fused (bf16) against torch.nn.Transformer(src, src) in fp32, eval mode, batch_first=False --
+    the exact module MobileViT builds (model_block.py:270-271).  bf16 storage of every intermediate: rms < 3 %."""
+    import torch.nn as nn
+    from ccnet_amd import ops
+    torch.manual_seed(S * 100 + N)
+    tr = nn.Transformer(d_model=256, nhead=2, num_encoder_layers=n_enc, num_decoder_layers=n_dec, dim_feedforward=1024).eval()
+    with torch.no_grad():
+        for name, prm in tr.named_parameters():  # non-trivial biases and LayerNorm parameters
+            if prm.dim() == 1:
+                prm.copy_(torch.randn_like(prm) * 0.1 + (1.0 if "norm" in name and name.endswith("weight") else 0.0))
+    sd = {"t." + k: v for k, v in tr.state_dict().items()}
+    src = torch.randn(S, N, 256) * 0.8
+    with torch.no_grad():
+        ref = tr(src, src)
+    wst, pvec, fpw = ops.pack_transformer(sd, "t", n_enc, n_dec, "cuda")
+    x = src.reshape(S * N, 256).to("cuda", torch.bfloat16).contiguous()
+    out = torch.empty_like(x)
+    ops.transformer_fused(x, 256, out, 256, S, N, wst, fpw, pvec, n_enc, n_dec)
+    torch.cuda.synchronize()
+    got = out.float().cpu().reshape(S, N, 256)
+    err = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert err < 0.03, "rms rel err %.3e" % err
+    assert float((got - ref).abs().max()) < 0.25
+
+
+def test_transformer_fused_rejects_other_shapes():
+    from ccnet_amd import _lib
+    L = _lib.lib()
+    t = torch.zeros(64, 256, device="cuda", dtype=torch.bfloat16)
+    f = torch.zeros(4, device="cuda")
+    rc = L.ccnet_transformer_fused(t.data_ptr(), 256, t.data_ptr(), 256, 65, 1, 256, 2, 1024, t.data_ptr(), 0, f.data_ptr(), 0, 0, None)
+    assert rc != 0 and b"S" in L.ccnet_last_error()
+    rc = L.ccnet_transformer_fused(t.data_ptr(), 256, t.data_ptr(), 256, 8, 1, 512, 2, 1024, t.data_ptr(), 0, f.data_ptr(), 0, 0, None)
+    assert rc != 0
