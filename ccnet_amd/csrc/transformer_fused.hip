@@ -56,7 +56,7 @@ __device__ __forceinline__ int xoff(int row, int chunk) { return row * 512 + (((
 // address terms are immediates.  `start` = ring slot of the first fragment; a compile-time constant after unrolling.
 template <int NTW>
 __device__ __forceinline__ void mm256(f32x4 (&acc)[4][NTW], const unsigned char* src, u32x4 (&ring)[RING], const unsigned char*& wp,
-                                      const int (&lx)[4], int start = 0) {
+                                      int loff, const int (&lx)[4], int start = 0) {
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
         u32x4 xb[4];
@@ -68,7 +68,7 @@ __device__ __forceinline__ void mm256(f32x4 (&acc)[4][NTW], const unsigned char*
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
                 acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[slot]), __builtin_bit_cast(bf16x8, xb[mt]), acc[mt][j], 0, 0, 0);
-            ring[slot] = *(const u32x4*)(wp + RING * 1024);  // refill with the fragment RING ahead
+            ring[slot] = *(const u32x4*)(wp + RING * 1024 + loff);  // refill with the fragment RING ahead (wp is wave uniform)
 #ifndef TF_NOADVANCE  // perf ablation: re-read the same fragments (cache hits) instead of streaming
             wp += 1024;
 #endif
@@ -105,10 +105,11 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
     for (int k4 = 0; k4 < 4; ++k4) lx[k4] = fr * 512 + ((((k4 * 4) ^ fr ^ fq) & 15) << 4);
 
     // ---- weight ring
-    const unsigned char* wp = p.wstream + (size_t)wave * (size_t)(p.frags_per_wave + RING) * 1024 + lane * 16;
+    const unsigned char* wp = p.wstream + (size_t)wave * (size_t)(p.frags_per_wave + RING) * 1024;  // wave uniform
+    const int loff = lane * 16;
     u32x4 ring[RING];
 #pragma unroll
-    for (int i = 0; i < RING; ++i) ring[i] = *(const u32x4*)(wp + i * 1024);
+    for (int i = 0; i < RING; ++i) ring[i] = *(const u32x4*)(wp + i * 1024 + loff);
     const float* pp = p.params;
 
     // tokens of this position -> X (rows >= S are zero)
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
             for (int part = 0; part < 3; ++part) {
                 f32x4 acc[4][1];
                 zero<1>(acc);
-                mm256<1>(acc, part == 0 ? XQ : XKV, ring, wp, lx, ((h * 3 + part) * 8) % RING);
+                mm256<1>(acc, part == 0 ? XQ : XKV, ring, wp, loff, lx, ((h * 3 + part) * 8) % RING);
                 unsigned short* dstT = part == 0 ? Qs : part == 1 ? Ks : Vs;
                 const int c0 = wave * 16 + fq * 4;  // column inside the head
                 const float4 bv = *(const float4*)(in_bias + part * E + h * HD + c0);
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
         }
         f32x4 acc[4][2];
         zero<2>(acc);
-        mm256<2>(acc, AO, ring, wp, lx);
+        mm256<2>(acc, AO, ring, wp, loff, lx);
         to_z(acc, out_bias);
         __syncthreads();
     };
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
         for (int c = 0; c < FF / 256; ++c) {
             f32x4 acc1[4][2];
             zero<2>(acc1);
-            mm256<2>(acc1, X, ring, wp, lx);
+            mm256<2>(acc1, X, ring, wp, loff, lx);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n0 = wave * 32 + j * 16 + fq * 4;  // column inside the chunk
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
                 }
             }
             __syncthreads();
-            mm256<2>(acc2, Tb, ring, wp, lx);
+            mm256<2>(acc2, Tb, ring, wp, loff, lx);
             __syncthreads();  // before the next chunk (or Z) overwrites the hidden tile
         }
         to_z(acc2, b2);
