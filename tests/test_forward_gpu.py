@@ -154,3 +154,19 @@ def test_bf16_detection_level_agreement():
     n_b = sum(d.shape[0] for d in res["bf16"][0])
     assert abs(n_f - n_b) <= 0.05 * n_f
     assert v_b[0] > 0.8 and m_b > 0.5, "bf16 mAP50 %.3f mAP50-95 %.3f" % (v_b[0], m_b)
+
+
+def test_full_size_batch_independence_net_deploy():
+    """BASELINE config 3 size (640^2, many images): net_deploy is per-image independent in eval mode, and
+    the implicit-GEMM K reduction of a pixel does not depend on which tile or batch it sits in, so image i of a large batch
+    must equal the same image run alone -- bit for bit, in bf16.  Size-independent property at full size."""
+    from ccnet_amd import synth
+    net = _model("net_deploy", 0.33, 0.5, 6, "bf16")
+    B = 32
+    x = torch.cat([synth.synth_images(4, 640, 640, seed=10 + i) for i in range(B // 4)], 0).to("cuda")
+    big = [o.clone() for o in net(x)]
+    for i in (0, 17, B - 1):
+        one = net(x[i:i + 1].contiguous())
+        torch.cuda.synchronize()
+        for lvl, (a, b) in enumerate(zip(big, one)):
+            assert torch.equal(a[i:i + 1], b), "image %d level %d differs between bs%d and bs1" % (i, lvl, B)

@@ -448,3 +448,53 @@ def test_transformer_fused_rejects_other_shapes():
     assert rc != 0 and b"S" in L.ccnet_last_error()
     rc = L.ccnet_transformer_fused(t.data_ptr(), 256, t.data_ptr(), 256, 8, 1, 512, 2, 1024, t.data_ptr(), 0, f.data_ptr(), 0, 0, None)
     assert rc != 0
+
+
+def test_nms_full_size_properties():
+    """SURVEY 8(d) NMS microbench at full size (16 images x 10 000 candidates): too slow for the scalar oracle, so check
+    size-independent properties: kept scores are non-increasing, no kept same-class pair overlaps above the threshold,
+    every rejected box is covered by a kept higher-scoring same-class box, and NMS of the kept set keeps all of it."""
+    from ccnet_amd.utils import bbox
+    rng = np.random.RandomState(1)
+    B, n, thr = 16, 10000, 0.6
+    cand = np.zeros((B, n, 7), np.float32)
+    c = rng.uniform(0, 1, (B, n, 2))
+    wh = np.exp(rng.normal(math.log(0.05), 0.5, (B, n, 2)))
+    cand[..., 0:2] = c - wh / 2
+    cand[..., 2:4] = c + wh / 2
+    cand[..., 4] = rng.uniform(0, 1, (B, n))
+    cand[..., 5] = 1.0
+    cand[..., 6] = rng.randint(0, 6, (B, n))
+    ct = torch.from_numpy(cand).to(DEV)
+    counts = torch.full((B,), n, dtype=torch.int32, device=DEV)
+    keep = bbox.nms_keep_indices(ct, counts, thr)
+
+    def iou(a, b):  # (p,4) x (q,4) on the GPU, torch fp32 reference arithmetic
+        lt = torch.maximum(a[:, None, :2], b[None, :, :2])
+        rb = torch.minimum(a[:, None, 2:], b[None, :, 2:])
+        whi = (rb - lt).clamp(min=0)
+        inter = whi[..., 0] * whi[..., 1]
+        aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+        ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        return inter / (aa[:, None] + ab[None, :] - inter)
+
+    for b in (0, 7, 15):
+        k = torch.from_numpy(keep[b]).to(DEV)
+        assert 0 < k.numel() < n
+        boxes, score, cls = ct[b, :, :4], ct[b, :, 4], ct[b, :, 6]
+        ks = score[k]
+        assert bool((ks[:-1] >= ks[1:]).all())
+        m = iou(boxes[k], boxes[k])
+        same = cls[k][:, None] == cls[k][None, :]
+        m = torch.where(same, m, torch.zeros_like(m))
+        m.fill_diagonal_(0)
+        assert float(m.max()) <= thr + 1e-6
+        rej = torch.ones(n, dtype=torch.bool, device=DEV)
+        rej[k] = False
+        r = rej.nonzero().flatten()
+        mr = iou(boxes[r], boxes[k])
+        cover = (mr > thr - 1e-6) & (cls[r][:, None] == cls[k][None, :]) & (score[k][None, :] >= score[r][:, None])
+        assert bool(cover.any(dim=1).all())
+        sub = ct[b:b + 1, k].contiguous()
+        again = bbox.nms_keep_indices(sub, torch.tensor([k.numel()], dtype=torch.int32, device=DEV), thr)[0]
+        assert again.shape[0] == k.numel() and np.array_equal(again, np.arange(k.numel()))
