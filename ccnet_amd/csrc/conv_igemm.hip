@@ -21,69 +21,12 @@
 // register-only and stores 8 B (bf16) / 16 B (fp32) per lane -- an LDS-transposed epilogue cost as much as all MFMAs.
 #include <stdlib.h>
 #include <type_traits>
-#include "common.h"
+#include "conv_common.h"
 
 int ccnet_conv2d_generic(const ccnet_conv_desc* d, ccnet_stream stream);  // conv_generic.hip
+int ccnet_conv2d_patch_try(const ccnet_conv_desc* d, const double* span, int kpad, ccnet_launch_fn* launch);  // conv_patch.hip
 
 namespace {
-
-constexpr int BKB = 128;  // bytes of K per row per step
-
-// native vector type for everything staged through registers (arrays of HIP's uint4 struct end up in scratch/LDS)
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-struct SegQ {
-    const unsigned char* ptr;  // first element of the slice (channel offset applied)
-    unsigned ldcB;             // pixel stride in bytes
-    int shift, Hs, Ws;
-    unsigned span;             // bytes addressable from ptr (< 2^31)
-};
-
-struct ConvQ {
-    SegQ seg[2];
-    int nseg, Ctot, C0;
-    int H, W, kh, kw, stride, pad, Ho, Wo, Cout;
-    unsigned M, ntiles;
-    unsigned magicW, shiftW, magicH, shiftH;  // n / Wo, n / Ho by multiply-high
-    const unsigned char* weight;
-    int Kpad, nk;
-    const float* bias;
-    int act;
-    const unsigned char* res_ptr;
-    int res_ldc, res_coff;
-    unsigned char* out_ptr;
-    int out_ldc, out_coff;
-    int vec_out;
-};
-
-template <typename T> struct Frag;
-template <> struct Frag<__bf16> {
-    static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-    }
-};
-template <> struct Frag<float> {
-    static __device__ __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x4& acc) {
-        f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], acc, 0, 0, 0);
-    }
-};
-
-typedef __attribute__((address_space(3))) void lds_void;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * BKB + ((chunk ^ ((row >> 1) & 7)) << 4); }
-__device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned magic, unsigned shift) { return (__umulhi(n, magic) + n) >> shift; }
-
-
-// ACT: activation compiled into the epilogue (CCNET_ACT_*), or ACT_RUNTIME to branch on p.act per element.
-constexpr int ACT_RUNTIME = -1;
-
-#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n) : "memory")
 
 // Tile BM x BN, WM x WN waves of 64 lanes, NST LDS stages (the DMA runs NST-1 K steps ahead of the MFMAs).
 template <typename T, typename OutT, int BM, int BN, int WM, int WN, int NST, int ACT>
@@ -389,6 +332,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvQ
     bool pending = false;
     unsigned pend_tile = 0;
     int stores_prev = 0;  // 1: the previous trip issued exactly S stores; 0: none; -1: an uncounted number
+#ifdef CC_STAMP
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
     for (unsigned j = 0;; ++j) {  // one extra trip drains the last tile's epilogue (single inlined epilogue body)
         // step j + NST - 1 goes into the buffer that step j - 1 read, behind that step's barrier
         bool dma_now = false;
@@ -398,6 +344,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvQ
             ++issued;
             dma_now = true;
         }
+        STAMP(0);
         int stores_now = 0;
         if (pending) {
             const bool full = n_full && (pend_tile + 1) * BM <= p.M;
@@ -405,8 +352,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvQ
             stores_now = full ? 1 : -1;
             pending = false;
         }
+        STAMP(1);
         if (j == total) break;
         compute((int)(j % NST));
+        STAMP(2);
         // Step j+1 must have landed before the barrier that lets every wave read it.  Vector memory operations retire
         // in order, so it is enough to allow as many outstanding operations as were issued AFTER its DMA: with two
         // stages that is this trip's stores; with three, also the previous trip's stores and this trip's DMA.
@@ -429,8 +378,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvQ
             }
         }
         stores_prev = stores_now;
+        STAMP(3);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        STAMP(4);
         if (++c_k == p.nk) {
             c_k = 0;
             pending = true;
@@ -438,6 +389,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvQ
             c_tile += tstride;
         }
     }
+#ifdef CC_STAMP
+    if (lane == 0 && wave == 1)
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
+#endif
 }
 
 int pick_bn(int Cout) { return Cout <= 16 ? 16 : Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128; }
@@ -513,6 +468,18 @@ int conv_big_policy() {  // CCNET_CONV_BIG=0/1 forces the tile choice (tuning ai
 }
 
 }  // namespace
+
+#ifdef CC_STAMP
+extern "C" int ccnet_debug_stamps(unsigned long long* out8, int reset) {
+    CC_HIP(hipDeviceSynchronize());
+    CC_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        CC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)));
+    }
+    return CCNET_OK;
+}
+#endif
 
 extern "C" int ccnet_conv_pack_dims(int dtype, int Cout, int K, int* Cout_pad, int* Kpad) {
     CC_REQUIRE(cc_dtype_ok(dtype) && Cout > 0 && K > 0 && Cout_pad && Kpad, "conv_pack_dims: bad arguments");
@@ -596,6 +563,13 @@ extern "C" int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream) {
         vec = vec && (r.ldc % rg) == 0 && (r.coff % rg) == 0 && ((uintptr_t)r.ptr % 16) == 0 && (r.ldc % 8) == 0 && (r.coff % 8) == 0;
     }
     p.vec_out = vec ? 1 : 0;
+    const double flops = 2.0 * (double)M * d->Cout * d->kh * d->kw * ctot;
+    const double bytes = ((double)d->B * d->H * d->W * ctot + (double)d->Cout * d->kh * d->kw * ctot) * es +
+                         (double)M * d->Cout * (cc_esize(d->out_dtype) + (d->residual.ptr ? es : 0));
+    {   // 3x3 s1 p1 and SpaceToDepth (6x6 s2 p2) layers on 16-aligned widths: LDS halo-patch kernel
+        ccnet_launch_fn patch_fn;
+        if (ccnet_conv2d_patch_try(d, span, kpad, &patch_fn)) return ccnet_submit(patch_fn, stream, CCNET_OP_CONV, flops, bytes);
+    }
     const int bn = pick_bn(d->Cout);
     const int dt = d->dtype, odt = d->out_dtype;
     const long long tiles256 = ((M + 255) / 256) * ((d->Cout + bn - 1) / bn);
@@ -606,7 +580,5 @@ extern "C" int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream) {
             if (dt == CCNET_BF16) return odt == CCNET_BF16 ? launch<__bf16, __bf16>(p, bn, big, st) : launch<__bf16, float>(p, bn, big, st);
             return launch<float, float>(p, bn, big, st);
         },
-        stream, CCNET_OP_CONV, 2.0 * (double)M * d->Cout * d->kh * d->kw * ctot,
-        ((double)d->B * d->H * d->W * ctot + (double)d->Cout * d->kh * d->kw * ctot) * es +
-            (double)M * d->Cout * (cc_esize(d->out_dtype) + (d->residual.ptr ? es : 0)));
+        stream, CCNET_OP_CONV, flops, bytes);
 }

@@ -42,3 +42,10 @@ for name in names:
     fl = 2.0 * B * Ho * Wo * cout * cin * k * k
     by = (B * H * W * cin + B * Ho * Wo * cout + cout * cin * k * k) * 2
     print("%-16s %8.3f ms  %7.1f TF/s  %7.1f GB/s" % (name, ms, fl / ms / 1e9, by / ms / 1e6), flush=True)
+    from ccnet_amd import _lib
+    if hasattr(_lib.lib(), "ccnet_debug_stamps"):  # diagnostic build (-DCC_STAMP): share of wave time per main-loop phase
+        import ctypes
+        st = (ctypes.c_ulonglong * 8)()
+        _lib.lib().ccnet_debug_stamps(st, 1)
+        tot = float(sum(st[:5])) or 1.0
+        print("   phases: gather %.1f%%  epilogue %.1f%%  lds+mfma %.1f%%  wait-dma %.1f%%  barrier %.1f%%" % tuple(100.0 * st[i] / tot for i in range(5)))

@@ -59,6 +59,13 @@ CONV_CASES = [
     (256, 512, 1, 1, 0, 7, 7, "relu6", False),
     (8, 24, 3, 1, 1, 9, 9, "none", False),
     (128, 5, 1, 1, 0, 20, 20, "none", False),
+    # shapes the LDS halo-patch kernel takes (3x3 s1 p1 / 6x6 s2 p2, output width % 16 == 0, Cout >= 64)
+    (128, 128, 3, 1, 1, 24, 32, "silu", True),
+    (64, 192, 3, 1, 1, 20, 16, "silu", False),
+    (128, 64, 3, 1, 1, 8, 48, "none", False),
+    (256, 80, 3, 1, 1, 5, 16, "relu", True),
+    (64, 128, 6, 2, 2, 32, 64, "silu", False),
+    (128, 64, 6, 2, 2, 20, 32, "none", True),
 ]
 
 
@@ -115,6 +122,26 @@ def test_conv2d_two_segments_with_upsample(code):
         cat = torch.cat([F.interpolate(q(a, code), scale_factor=2, mode="nearest"), q(bb, code)], 1)
         ref = F.silu(F.conv2d(cat, q(w, code), bias, 1, k // 2))
         assert rel(from_nhwc(out, 0, 48), ref) < tol(code)
+
+
+@pytest.mark.parametrize("code", [0, 1])
+def test_conv3x3_two_segments_patch_kernel(code):
+    """3x3 over torch.cat([a, b], 1) at a 16-aligned width (MobileViT conv4, network/model_block.py:296-297): the halo-patch
+    kernel switches segment per 128-byte channel chunk."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 12, 32
+    a = torch.randn(B, 64, H, W, generator=g)
+    bb = torch.randn(B, 128, H, W, generator=g)
+    w = torch.randn(96, 192, 3, 3, generator=g) / math.sqrt(192 * 9)
+    bias = torch.randn(96, generator=g) * 0.1
+    pc = ops.PackedConv(w, bias, code, DEV)
+    ta, tb = to_nhwc(a, code, ldc=80, coff=16), to_nhwc(bb, code)
+    out = torch.zeros(B, H, W, 96, dtype=tdt(code), device=DEV)
+    ops.conv2d([ops.sl(ta, 16, 64), ops.sl(tb)], pc, B, H, W, 1, 1, ops.sl(out), "silu")
+    torch.cuda.synchronize()
+    ref = F.silu(F.conv2d(torch.cat([q(a, code), q(bb, code)], 1), q(w, code), bias, 1, 1))
+    assert rel(from_nhwc(out, 0, 96), ref) < tol(code)
 
 
 @pytest.mark.parametrize("code", [0, 1])
