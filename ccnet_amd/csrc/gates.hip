@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void cbam_mlp_kernel(const float* partial, int
     const int b = blockIdx.x, t = threadIdx.x;
     for (int c = t; c < C; c += 256) {
         float s = 0.0f, m = -INFINITY;
+#pragma unroll 8
         for (int k = 0; k < nchunk; ++k) {
             const float* src = partial + (((size_t)b * nchunk + k) * 2) * C;
             s += src[c];
@@ -87,13 +88,30 @@ __global__ __launch_bounds__(256) void cbam_mlp_kernel(const float* partial, int
     }
     __syncthreads();
     const int lane = t & 63, wave = t >> 6;
-    for (int j = wave; j < 2 * Cr; j += 4) {
-        const float* v = (j < Cr) ? avg : mx;
-        const float* wr = fc1 + (size_t)(j < Cr ? j : j - Cr) * C;
-        float a = 0.0f;
-        for (int c = lane; c < C; c += 64) a = fmaf(wr[c], v[c], a);
-        a = wave_sum(a);
-        if (lane == 0) hid[j] = fmaxf(a, 0.0f);
+    // hidden unit j (< Cr: on the average, >= Cr: on the maximum); 8 units per wave pass so that 8 rows of fc1 are in flight
+    for (int j0 = wave * 8; j0 < 2 * Cr; j0 += 32) {
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = 0.0f;
+        // row pointers first (clamped, so that no load sits behind a branch: a load under `if` is waited for on the spot)
+        const float* wrow[8];
+        const float* vsrc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = min(j0 + u, 2 * Cr - 1);
+            wrow[u] = fc1 + (size_t)(j < Cr ? j : j - Cr) * C;
+            vsrc[u] = j < Cr ? avg : mx;
+        }
+#pragma unroll 4
+        for (int c = lane; c < C; c += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = fmaf(wrow[u][c], vsrc[u][c], a[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float r = wave_sum(a[u]);
+            if (lane == 0 && j0 + u < 2 * Cr) hid[j0 + u] = fmaxf(r, 0.0f);
+        }
     }
     __syncthreads();
     for (int c = t; c < C; c += 256) {
@@ -193,6 +211,7 @@ __global__ __launch_bounds__(256) void eca_gate_kernel(const float* partial, int
     const int b = blockIdx.x, t = threadIdx.x;
     for (int c = t; c < C; c += 256) {
         float s = 0.0f;
+#pragma unroll 8
         for (int k = 0; k < nchunk; ++k) s += partial[(((size_t)b * nchunk + k) * 2) * C + c];
         avg[c] = s / (float)HW;
     }
