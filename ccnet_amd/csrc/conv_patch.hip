@@ -400,7 +400,8 @@ int ccnet_conv2d_patch_try(const ccnet_conv_desc* d, const double* span, int kpa
     if (d->Cout < 64 || (d->Wo % TW) != 0) return 0;
     int ctot = 0;
     for (int s = 0; s < d->nseg; ++s) {
-        if (d->in[s].shift != 0 || (d->in[s].C % bk) != 0 || span[s] >= 2147483648.0) return 0;
+        if (d->in[s].shift != 0 || span[s] >= 2147483648.0) return 0;
+        if (!s2d && (d->in[s].C % bk) != 0) return 0;  // s2d: its own channel rule below
         ctot += d->in[s].C;
     }
     if (s2d) {

@@ -15,7 +15,7 @@ for line in open(log):
 n = len(ops)
 
 def per_dispatch(path):
-    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "conv_generic" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv_patch", "conv_generic"))]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return [float(r["Counter_Value"]) * 1024.0 for r in rows]
 
