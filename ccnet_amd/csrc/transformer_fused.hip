@@ -84,6 +84,17 @@ __device__ __forceinline__ void zero(f32x4 (&acc)[4][NTW]) {
         for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+#ifdef TF_STAMP  // diagnostic build: cycles per phase (0 GEMM, 1 epilogue, 2 barrier, 3 attention core, 4 LayerNorm)
+__device__ unsigned long long g_tf_stamps[8];
+#define TS(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_last; st_last = n_; } while (0)
+#define TPH(i) st_ph = (i)
+#define TSYNC() do { TS(st_ph); __syncthreads(); TS(2); } while (0)
+#else
+#define TS(i)
+#define TPH(i)
+#define TSYNC() __syncthreads()
+#endif
+
 __device__ __forceinline__ uint2 pack4(const float* v) { return make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
 
 // 8 waves (two per SIMD, so that one wave's LDS / VALU / barrier time hides under the other's MFMAs).  Wave w owns
@@ -111,6 +122,10 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
 #pragma unroll
     for (int i = 0; i < RING; ++i) ring[i] = *(const u32x4*)(wp + i * 1024 + loff);
     const float* pp = p.params;
+#ifdef TF_STAMP
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+    int st_ph = 1;
+#endif
 
     // tokens of this position -> X (rows >= S are zero)
     auto load_src = [&]() __attribute__((always_inline)) {
@@ -122,23 +137,53 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
         }
     };
 
-    // Z (pre-LayerNorm, padded rows in T) -> LayerNorm -> dst (swizzled operand) and optionally global rows
-    auto layernorm = [&](unsigned char* dst, const float* gb, bool to_global) __attribute__((always_inline)) {
-        const float4 g = *(const float4*)(gb + lane * 4);
-        const float4 b = *(const float4*)(gb + E + lane * 4);
-#pragma unroll 2
-        for (int r = 0; r < SM / NW; ++r) {
-            const int row = wave * (SM / NW) + r;
-            const uint2 raw = *(const uint2*)(Tb + (row * ZLD + lane * 4) * 2);
-            float v[4] = {bf16_bits_to_f32(raw.x & 0xFFFFu), bf16_bits_to_f32(raw.x >> 16), bf16_bits_to_f32(raw.y & 0xFFFFu), bf16_bits_to_f32(raw.y >> 16)};
-            const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / E);
-            float d[4] = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
-            const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / E);
-            const float rs = rsqrtf(var + 1e-5f);
-            float o[4] = {d[0] * rs * g.x + b.x, d[1] * rs * g.y + b.y, d[2] * rs * g.z + b.z, d[3] * rs * g.w + b.w};
-            const uint2 pk = pack4(o);
-            *(uint2*)(dst + xoff(row, lane >> 1) + (lane & 1) * 8) = pk;
-            if (to_global && row < p.S) *(uint2*)(p.out + ((size_t)((size_t)row * p.N + n) * p.out_ld + lane * 4) * 2) = pk;
+    // LayerNorm of the 64 rows of Z (pre-LayerNorm sums, padded rows in T) or of X itself -> dst (swizzled operand) and
+    // optionally the global output.  Lane = row, wave = 32-channel slice: each lane sums its slice serially, the 8 slices
+    // of a row meet through a 4 KB LDS table (one barrier) -- no cross-lane shuffles (a 64-lane butterfly is 6 dependent
+    // ds_bpermute per reduction and made LayerNorm a quarter of the kernel).  Statistics in fp32, one pass (sum, sum of
+    // squares).
+    float2* lnpart = (float2*)(sm + OFF_P);  // [64 rows][8 slices]; the P tiles are idle outside the attention core
+    auto layernorm = [&](unsigned char* dst, const float* gb, bool from_x, bool to_global) __attribute__((always_inline)) {
+        TPH(4);
+        const int row = lane;
+        float v[32];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32x4 raw = from_x ? *(const u32x4*)(X + xoff(row, 4 * wave + q)) : *(const u32x4*)(Tb + (row * ZLD + 32 * wave + 8 * q) * 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[8 * q + 2 * e] = bf16_bits_to_f32(raw[e] & 0xFFFFu);
+                v[8 * q + 2 * e + 1] = bf16_bits_to_f32(raw[e] >> 16);
+            }
+        }
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+        lnpart[row * NW + wave] = make_float2(s1, s2);
+        TSYNC();
+        TPH(4);
+        float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 2) {
+            const float4 pr = *(const float4*)(&lnpart[row * NW + w]);
+            t1 += pr.x + pr.z;
+            t2 += pr.y + pr.w;
+        }
+        const float mean = t1 * (1.0f / E);
+        const float var = fmaxf(t2 * (1.0f / E) - mean * mean, 0.0f);
+        const float rs = rsqrtf(var + 1e-5f);
+        const float* g = gb + 32 * wave;       // wave-uniform: scalar loads
+        const float* bt = gb + E + 32 * wave;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u32x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 8 * q + 2 * e;
+                pk[e] = pack_bf16x2((v[c] - mean) * rs * g[c] + bt[c], (v[c + 1] - mean) * rs * g[c + 1] + bt[c + 1]);
+            }
+            *(u32x4*)(dst + xoff(row, 4 * wave + q)) = pk;
+            if (to_global && row < p.S) *(u32x4*)(p.out + ((size_t)((size_t)row * p.N + n) * p.out_ld + 32 * wave + 8 * q) * 2) = pk;
         }
     };
 
@@ -174,7 +219,7 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
             for (int part = 0; part < 3; ++part) {
                 f32x4 acc[4][1];
                 zero<1>(acc);
-                mm256<1>(acc, part == 0 ? XQ : XKV, ring, wp, loff, lx, ((h * 3 + part) * 8) % RING);
+                mm256<1>(acc, part == 0 ? XQ : XKV, ring, wp, loff, lx, ((h * 3 + part) * 8) % RING); TS(0); TPH(1);
                 unsigned short* dstT = part == 0 ? Qs : part == 1 ? Ks : Vs;
                 const int c0 = wave * 16 + fq * 4;  // column inside the head
                 const float4 bv = *(const float4*)(in_bias + part * E + h * HD + c0);
@@ -184,7 +229,8 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
                     *(uint2*)(dstT + (mt * 16 + fr) * QLD + c0) = pack4(v);
                 }
             }
-            __syncthreads();
+            TSYNC();
+            TPH(3);
             // scores of query tile qt against all 64 keys (both waves of a query tile compute them)
             f32x4 s[4];
 #pragma unroll
@@ -256,13 +302,13 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
                     *(unsigned short*)(AO + xoff(row, col >> 3) + (col & 7) * 2) = (unsigned short)f32_to_bf16_bits(o[i][r] * inv[r]);
                 }
             }
-            __syncthreads();  // every wave is done with this head's K/V (and AO is complete after the second head)
+            TSYNC();  // every wave is done with this head's K/V (and AO is complete after the second head)
         }
         f32x4 acc[4][2];
         zero<2>(acc);
-        mm256<2>(acc, AO, ring, wp, loff, lx);
+        mm256<2>(acc, AO, ring, wp, loff, lx); TS(0); TPH(1);
         to_z(acc, out_bias);
-        __syncthreads();
+        TSYNC();
     };
 
     auto ffn = [&]() __attribute__((always_inline)) {
@@ -274,7 +320,7 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
         for (int c = 0; c < FF / 256; ++c) {
             f32x4 acc1[4][2];
             zero<2>(acc1);
-            mm256<2>(acc1, X, ring, wp, loff, lx);
+            mm256<2>(acc1, X, ring, wp, loff, lx); TS(0); TPH(1);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n0 = wave * 32 + j * 16 + fq * 4;  // column inside the chunk
@@ -286,52 +332,56 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
                     *(uint2*)(Tb + xoff(mt * 16 + fr, n0 >> 3) + (n0 & 4) * 2) = pack4(v);
                 }
             }
-            __syncthreads();
-            mm256<2>(acc2, Tb, ring, wp, loff, lx);
-            __syncthreads();  // before the next chunk (or Z) overwrites the hidden tile
+            TSYNC();
+            mm256<2>(acc2, Tb, ring, wp, loff, lx); TS(0); TPH(1);
+            TSYNC();  // before the next chunk (or Z) overwrites the hidden tile
         }
         to_z(acc2, b2);
-        __syncthreads();
+        TSYNC();
     };
-    auto add_ln = [&](unsigned char* dst, bool to_global) __attribute__((always_inline)) {
-        layernorm(dst, pp, to_global);
+    auto add_ln = [&](unsigned char* dst, bool from_x, bool to_global) __attribute__((always_inline)) {
+        layernorm(dst, pp, from_x, to_global);
         pp += 2 * E;
-        __syncthreads();
-    };
-    // plain LayerNorm of X (encoder.norm / decoder.norm): copy X to Z first
-    auto ln_of_x = [&](unsigned char* dst, bool to_global) __attribute__((always_inline)) {
-        for (int r = 0; r < SM / NW; ++r) {
-            const int row = wave * (SM / NW) + r;
-            *(uint2*)(Tb + (row * ZLD + lane * 4) * 2) = *(const uint2*)(X + xoff(row, lane >> 1) + (lane & 1) * 8);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();  // rows are wave private
-        add_ln(dst, to_global);
+        TSYNC();
     };
 
     load_src();
-    __syncthreads();
+    TSYNC();
     for (int l = 0; l < p.n_enc; ++l) {
         attention(X, X);
-        add_ln(X, false);
+        add_ln(X, false, false);
         ffn();
-        add_ln(X, false);
+        add_ln(X, false, false);
     }
-    ln_of_x(MEM, false);
+    add_ln(MEM, true, false);  // encoder.norm
     load_src();  // nn.Transformer(src, src): the decoder starts from the same tokens
-    __syncthreads();
+    TSYNC();
     for (int l = 0; l < p.n_dec; ++l) {
         attention(X, X);
-        add_ln(X, false);
+        add_ln(X, false, false);
         attention(X, MEM);
-        add_ln(X, false);
+        add_ln(X, false, false);
         ffn();
-        add_ln(X, false);
+        add_ln(X, false, false);
     }
-    ln_of_x(X, true);
+    add_ln(X, true, true);  // decoder.norm (dst X is scratch here; rows go to the output)
+#ifdef TF_STAMP
+    if (lane == 0 && wave == 1)
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_tf_stamps[i], st_acc[i]);
+#endif
 }
 
 }  // namespace
+
+#ifdef TF_STAMP
+extern "C" int ccnet_debug_tf_stamps(unsigned long long* out8) {
+    CC_HIP(hipDeviceSynchronize());
+    CC_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tf_stamps), sizeof(unsigned long long) * 8));
+    unsigned long long z[8] = {0};
+    CC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tf_stamps), z, sizeof(z)));
+    return CCNET_OK;
+}
+#endif
 
 extern "C" int ccnet_transformer_fused_frags(int n_enc, int n_dec, long long* frags_per_wave, long long* param_floats) {
     CC_REQUIRE(n_enc >= 0 && n_dec >= 0 && frags_per_wave && param_floats, "transformer_fused_frags: bad arguments");

@@ -21,3 +21,11 @@ for _ in range(10):
 e1.record()
 torch.cuda.synchronize()
 print("fused transformer S=%d N=%d: %.3f ms  (out rms %.3f)" % (S, N, e0.elapsed_time(e1) / 10, float(out.float().pow(2).mean().sqrt())), flush=True)
+
+from ccnet_amd import _lib
+if hasattr(_lib.lib(), "ccnet_debug_tf_stamps"):  # diagnostic build (-DTF_STAMP)
+    import ctypes
+    st = (ctypes.c_ulonglong * 8)()
+    _lib.lib().ccnet_debug_tf_stamps(st)
+    tot = float(sum(st[:5])) or 1.0
+    print("   phases: gemm %.1f%%  epilogue %.1f%%  barrier %.1f%%  attention core %.1f%%  layernorm %.1f%%" % tuple(100.0 * st[i] / tot for i in range(5)))
