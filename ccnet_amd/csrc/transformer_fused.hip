@@ -95,6 +95,27 @@ __device__ unsigned long long g_tf_stamps[8];
 #define TSYNC() __syncthreads()
 #endif
 
+// all-reduce over the 16 lanes of a DPP row (the lanes that share fq): xor-1 and xor-2 inside quads, then the two mirror
+// steps -- four DPP-modified VALU instructions instead of four ds_bpermute round trips
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_f<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_f<0x141>(v));  // row_half_mirror
+    v = fmaxf(v, dpp_f<0x140>(v));  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
+    return v;
+}
+
 __device__ __forceinline__ uint2 pack4(const float* v) { return make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
 
 // 8 waves (two per SIMD, so that one wave's LDS / VALU / barrier time hides under the other's MFMAs).  Wave w owns
@@ -255,8 +276,7 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
                     s[i][r] = v;
                     mx = fmaxf(mx, v);
                 }
-#pragma unroll
-                for (int o_ = 8; o_ > 0; o_ >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o_, 64));
+                mx = row16_max(mx);
                 float sum = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -264,8 +284,7 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
                     s[i][r] = pv;
                     sum += pv;
                 }
-#pragma unroll
-                for (int o_ = 8; o_ > 0; o_ >>= 1) sum += __shfl_xor(sum, o_, 64);
+                sum = row16_sum(sum);
                 inv[r] = 1.0f / sum;
             }
             // P: C layout -> LDS tile of this query tile -> A fragments.  The two waves of a query tile write identical
