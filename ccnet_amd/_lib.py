@@ -62,6 +62,8 @@ def lib():
         L.ccnet_plan_begin.argtypes = [C.POINTER(vp)]
         L.ccnet_plan_end.argtypes = []
         L.ccnet_plan_num_ops.argtypes = [vp]
+        L.ccnet_plan_set_lane.argtypes = [i32]
+        L.ccnet_plan_wait.argtypes = [i32, i32]
         L.ccnet_plan_run.argtypes = [vp, vp, vp]
         L.ccnet_plan_destroy.argtypes = [vp]
         L.ccnet_plan_op_info.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(f64), C.POINTER(f64)]

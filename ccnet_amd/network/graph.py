@@ -434,24 +434,34 @@ class Compiler:
 
     def head(self, feats):
         """Decoupled head (net.py:244-275).  Output per level: fp32 NHWC [B,h,w,5+nc] = [reg4 | obj1 | cls nc]."""
-        nc = self.c["nc"]
-        outs = []
-        for k, x in enumerate(feats):
-            s = self.base_conv("stems.%d" % k, [x])
-            wc, bcv = self.folded("cls_convs.%d.0" % k)
-            wr, brv = self.folded("reg_convs.%d.0" % k)
-            hc = wc.shape[0]
-            both = self.conv_w(torch.cat([wc, wr], 0), torch.cat([bcv, brv], 0), [s], 1, 1, self.act)
-            cls_f = self.base_conv("cls_convs.%d.1" % k, [both.part(0, hc)])
-            reg_f = self.base_conv("reg_convs.%d.1" % k, [both.part(hc, hc)])
-            out = self.new(5 + nc, x.H, x.W, torch.float32)
-            wreg, breg = self.folded("reg_preds.%d" % k, "plain")
-            wobj, bobj = self.folded("obj_preds.%d" % k, "plain")
-            self.conv_w(torch.cat([wreg, wobj], 0), torch.cat([breg, bobj], 0), [reg_f], 1, 0, "none", out=out.part(0, 5), out_dtype=F32)
-            wcls, bcls = self.folded("cls_preds.%d" % k, "plain")
-            self.conv_w(wcls, bcls, [cls_f], 1, 0, "none", out=out.part(5, nc), out_dtype=F32)
-            outs.append(out)
+        outs = [None] * len(feats)
+        # the levels are independent: the first (largest) stays on lane 0, the others run beside it on side lanes
+        for k in range(1, len(feats)):
+            ops.plan_wait(k, 0)
+            ops.plan_set_lane(k)
+            outs[k] = self.head_level(k, feats[k])
+        ops.plan_set_lane(0)
+        outs[0] = self.head_level(0, feats[0])
+        for k in range(1, len(feats)):
+            ops.plan_wait(0, k)
         return outs
+
+    def head_level(self, k, x):
+        nc = self.c["nc"]
+        s = self.base_conv("stems.%d" % k, [x])
+        wc, bcv = self.folded("cls_convs.%d.0" % k)
+        wr, brv = self.folded("reg_convs.%d.0" % k)
+        hc = wc.shape[0]
+        both = self.conv_w(torch.cat([wc, wr], 0), torch.cat([bcv, brv], 0), [s], 1, 1, self.act)
+        cls_f = self.base_conv("cls_convs.%d.1" % k, [both.part(0, hc)])
+        reg_f = self.base_conv("reg_convs.%d.1" % k, [both.part(hc, hc)])
+        out = self.new(5 + nc, x.H, x.W, torch.float32)
+        wreg, breg = self.folded("reg_preds.%d" % k, "plain")
+        wobj, bobj = self.folded("obj_preds.%d" % k, "plain")
+        self.conv_w(torch.cat([wreg, wobj], 0), torch.cat([breg, bobj], 0), [reg_f], 1, 0, "none", out=out.part(0, 5), out_dtype=F32)
+        wcls, bcls = self.folded("cls_preds.%d" % k, "plain")
+        self.conv_w(wcls, bcls, [cls_f], 1, 0, "none", out=out.part(5, nc), out_dtype=F32)
+        return out
 
     # ---- whole network
     def build(self, x_placeholder):
@@ -505,15 +515,33 @@ class Compiler:
             fpn2 = self.base_conv("reduce_conv2", [p2])
             p3 = self.csp("C3_p2", [fpn2.up(), g1], nn_, False)
             p2 = self.csp("C3_n2", [self.base_conv("bu_conv3", [p3], 2), fpn2], nn_, False)
+        early = not amff and not c["small"]
+        outs = [None, None, None]
+        if early:
+            # pan_out2 is final here: its head level (the largest, 80x80 at 640) runs on lane 1 beside the bottom-up path
+            ops.plan_wait(1, 0)
+            ops.plan_set_lane(1)
+            outs[0] = self.head_level(0, p2)
+            ops.plan_set_lane(0)
         p1 = self.csp("C3_n3", [self.down("bu_conv2", p2), fpn1], nn_, False, amff)
         if amff:
             p1 = self.eca("eca_pa2", p1)
+        if early:
+            ops.plan_wait(2, 0)
+            ops.plan_set_lane(2)
+            outs[1] = self.head_level(1, p1)
+            ops.plan_set_lane(0)
         p0 = self.csp("C3_n4", [self.down("bu_conv1", p1), fpn0], nn_, False, amff)
         if amff:
             p0 = self.eca("eca_pa3", p0)
             pan = (p2, p1, p0)
             p0, p1, p2 = self.asff("asff_1", 0, pan), self.asff("asff_2", 1, pan), self.asff("asff_3", 2, pan)
         tp["pan_out2"], tp["pan_out1"], tp["pan_out0"] = p2, p1, p0
+        if early:
+            outs[2] = self.head_level(2, p0)
+            ops.plan_wait(0, 1)
+            ops.plan_wait(0, 2)
+            return outs
         feats = (p3, p2, p1, p0) if c["small"] else (p2, p1, p0)
         return self.head(feats)
 

@@ -259,6 +259,14 @@ def nms(cand, counts, nmax, thr, image_hw, det, keep_idx, nkeep, workspace):
                           keep_idx.data_ptr(), nkeep.data_ptr(), workspace.data_ptr(), stream_ptr()))
 
 
+def plan_set_lane(lane):
+    check(lib().ccnet_plan_set_lane(lane))
+
+
+def plan_wait(dst_lane, src_lane):
+    check(lib().ccnet_plan_wait(dst_lane, src_lane))
+
+
 class Recorder:
     """with Recorder() as r: ...op wrappers...  -> r.plan is a replayable ccnet_plan handle."""
 

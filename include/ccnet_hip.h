@@ -167,6 +167,12 @@ typedef struct ccnet_plan ccnet_plan;
 int ccnet_plan_begin(ccnet_plan** plan);
 int ccnet_plan_end(void);
 int ccnet_plan_num_ops(const ccnet_plan* plan);
+/* Concurrency inside a plan (recording thread only).  Ops are recorded on the current lane (0..3, default 0 = the stream
+ * given to ccnet_plan_run; lanes 1..3 are side streams owned by the plan).  ccnet_plan_wait(dst, src) makes everything
+ * recorded later on lane dst wait for everything recorded so far on lane src.  The recorder must join every side lane back
+ * into lane 0 before ccnet_plan_end().  Used for the independent head levels / PAN branches (network/net.py:225-275). */
+int ccnet_plan_set_lane(int lane);
+int ccnet_plan_wait(int dst_lane, int src_lane);
 /* x_dev, if not NULL, replaces the image pointer of every recorded ccnet_stem_conv */
 int ccnet_plan_run(const ccnet_plan* plan, const float* x_dev, ccnet_stream stream);
 void ccnet_plan_destroy(ccnet_plan* plan);
