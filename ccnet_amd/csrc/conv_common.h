@@ -31,6 +31,7 @@ struct ConvQ {
     unsigned char* out_ptr;
     int out_ldc, out_coff;
     int vec_out;
+    int flat;  // 1x1 stride-1 unpadded, no upsampled operand: input pixel index == output pixel index
 };
 
 template <typename T> struct Frag;

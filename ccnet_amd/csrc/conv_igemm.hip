@@ -95,6 +95,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvQ
             const unsigned m = tile * BM + lr + RPI * i;
             const bool valid = m < p.M;
             const unsigned mm = valid ? m : 0u;
+            if (p.flat) {  // the thin 1x1 layers change tile every 1-4 K steps: no divisions, no tap loops for them
+                rowoff[0][i] = mm * p.seg[0].ldcB;
+                rowoff[1][i] = mm * p.seg[1].ldcB;
+                rmask[i] = valid ? 1ull : 0ull;
+                continue;
+            }
             const unsigned q1 = fastdiv(mm, p.magicW, p.shiftW);
             const int ox = (int)(mm - q1 * (unsigned)p.Wo);
             const unsigned b = fastdiv(q1, p.magicH, p.shiftH);
@@ -563,6 +569,7 @@ extern "C" int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream) {
         vec = vec && (r.ldc % rg) == 0 && (r.coff % rg) == 0 && ((uintptr_t)r.ptr % 16) == 0 && (r.ldc % 8) == 0 && (r.coff % 8) == 0;
     }
     p.vec_out = vec ? 1 : 0;
+    p.flat = (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && p.seg[0].shift == 0 && p.seg[1].shift == 0) ? 1 : 0;
     const double flops = 2.0 * (double)M * d->Cout * d->kh * d->kw * ctot;
     const double bytes = ((double)d->B * d->H * d->W * ctot + (double)d->Cout * d->kh * d->kw * ctot) * es +
                          (double)M * d->Cout * (cc_esize(d->out_dtype) + (d->residual.ptr ? es : 0));
