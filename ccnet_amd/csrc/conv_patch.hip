@@ -23,7 +23,9 @@
 
 namespace {
 
-constexpr int TH = 8, TW = 16, PW = TW + 2, PPIX = (TH + 2) * PW;  // 180 patch pixels
+// Tile geometry, template parameter MC: an MFMA m-tile is MR x MC output pixels (MR * MC = 16) and a block stacks 8 of them
+// vertically: 8 x 16 pixels (MC = 16, widths % 16 == 0) or 16 x 8 (MC = 8, widths % 8 == 0).  Both have a 180-pixel patch.
+constexpr int PPIX = 180;
 constexpr int PIECES = 6;                                          // LDS-DMA pieces per wave and chunk (24 x 8 rows = 192 >= 180)
 constexpr int PROWS = 4 * PIECES * 8;
 constexpr int PATCH_BYTES = PROWS * BKB;                           // 24576
@@ -46,6 +48,7 @@ struct PatchQ {
     unsigned char* out_ptr;
     int out_ldc, out_coff;
     int vec_out;
+    int mc;  // tile geometry (16 or 8), see PPIX
 };
 
 // One K step (chunk, tap) of the main loop with the tap as a compile-time constant; expanded nine times in the kernel so
@@ -73,11 +76,11 @@ struct PatchQ {
                 const unsigned char* Bs = bt0 + bpar * B_BYTES; \
                 u32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT]; \
 _Pragma("unroll") \
-                for (int i = 0; i < MT; ++i) fa0[i] = *(const u32x4*)(pt + abase[kx][0] + ((i + ky) * PW) * BKB); \
+                for (int i = 0; i < MT; ++i) fa0[i] = *(const u32x4*)(pt + abase[kx][0] + ((i * MR + ky) * PW) * BKB); \
 _Pragma("unroll") \
                 for (int j = 0; j < NT; ++j) fb0[j] = *(const u32x4*)(Bs + bbase[j][0]); \
 _Pragma("unroll") \
-                for (int i = 0; i < MT; ++i) fa1[i] = *(const u32x4*)(pt + abase[kx][1] + ((i + ky) * PW) * BKB); \
+                for (int i = 0; i < MT; ++i) fa1[i] = *(const u32x4*)(pt + abase[kx][1] + ((i * MR + ky) * PW) * BKB); \
 _Pragma("unroll") \
                 for (int j = 0; j < NT; ++j) fb1[j] = *(const u32x4*)(Bs + bbase[j][1]); \
                 __builtin_amdgcn_sched_barrier(0); \
@@ -102,8 +105,10 @@ _Pragma("unroll") \
             asm volatile("" ::: "memory"); \
     }
 
-template <typename T, typename OutT, int BN, int ACT>
+template <typename T, typename OutT, int BN, int MC, int ACT>
 __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
+    constexpr int MR = 16 / MC, TH = 8 * MR, TW = MC, PW = MC + 2;
+    static_assert((TH + 2) * PW == PPIX && (PW % 2) == 0, "patch geometry");
     constexpr int ES = (int)sizeof(T);
     constexpr int EPC = 16 / ES;
     constexpr int BK = BKB / ES;  // channels per chunk
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) abase[kx][h] = (wm * 4 * PW + fr + kx) * BKB + (((4 * h + fq) ^ (((fr + kx) >> 1) & 7)) << 4);
+        for (int h = 0; h < 2; ++h) abase[kx][h] = ((wm * 4 * MR + fr / MC) * PW + fr % MC + kx) * BKB + (((4 * h + fq) ^ (((fr % MC + kx) >> 1) & 7)) << 4);
     int bbase[NT][2];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -244,12 +249,12 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
         const unsigned per_img = (unsigned)(p.tiles_x * p.tiles_y);
         const unsigned b = tile / per_img, rem = tile - b * per_img;
         const int ty = (int)(rem / (unsigned)p.tiles_x), tx = (int)(rem - (unsigned)ty * p.tiles_x);
-        const int oy0 = ty * TH + wm * 4, ox = tx * TW + fr;
+        const int oy0 = ty * TH + wm * 4 * MR + fr / MC, ox = tx * TW + fr % MC;
         const bool full = n_full && !p.res_ptr && ty * TH + TH <= p.Hv && tx * TW + TW <= p.Wv;
         if (full) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const size_t m = ((size_t)b * p.Hv + oy0 + i) * p.Wv + ox;
+                const size_t m = ((size_t)b * p.Hv + oy0 + i * MR) * p.Wv + ox;
                 unsigned char* orow = p.out_ptr + (m * p.out_ldc + p.out_coff + nbase) * sizeof(OutT);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
         } else {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int oy = oy0 + i;
+                const int oy = oy0 + i * MR;
                 if (oy < p.Hv && ox < p.Wv) {
                     const size_t m = ((size_t)b * p.Hv + oy) * p.Wv + ox;
                     unsigned char* orow = p.out_ptr + (m * p.out_ldc + p.out_coff) * sizeof(OutT);
@@ -348,9 +353,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
     if (pending) epilogue(pend_tile);
 }
 
-template <typename T, typename OutT, int BN, int ACT>
+template <typename T, typename OutT, int BN, int MC, int ACT>
 int launch_patch_act(const PatchQ& p, hipStream_t st) {
-    auto kernel = conv_patch_kernel<T, OutT, BN, ACT>;
+    auto kernel = conv_patch_kernel<T, OutT, BN, MC, ACT>;
     constexpr int LDS = 2 * PATCH_BYTES + 2 * BN * BKB;
     static int cached[16] = {0};
     int dev = 0;
@@ -371,11 +376,15 @@ int launch_patch_act(const PatchQ& p, hipStream_t st) {
     return CCNET_OK;
 }
 
+template <typename T, typename OutT, int BN, int MC>
+int launch_patch_mc(const PatchQ& p, hipStream_t st) {
+    if (p.act == CCNET_ACT_SILU) return launch_patch_act<T, OutT, BN, MC, CCNET_ACT_SILU>(p, st);
+    if (p.act == CCNET_ACT_NONE) return launch_patch_act<T, OutT, BN, MC, CCNET_ACT_NONE>(p, st);
+    return launch_patch_act<T, OutT, BN, MC, ACT_RUNTIME>(p, st);
+}
 template <typename T, typename OutT, int BN>
 int launch_patch_bn(const PatchQ& p, hipStream_t st) {
-    if (p.act == CCNET_ACT_SILU) return launch_patch_act<T, OutT, BN, CCNET_ACT_SILU>(p, st);
-    if (p.act == CCNET_ACT_NONE) return launch_patch_act<T, OutT, BN, CCNET_ACT_NONE>(p, st);
-    return launch_patch_act<T, OutT, BN, ACT_RUNTIME>(p, st);
+    return p.mc == 16 ? launch_patch_mc<T, OutT, BN, 16>(p, st) : launch_patch_mc<T, OutT, BN, 8>(p, st);
 }
 
 bool patch_enabled() {  // CCNET_NO_PATCH_CONV=1 sends every conv to conv_igemm (tuning / bisecting aid)
@@ -397,7 +406,8 @@ int ccnet_conv2d_patch_try(const ccnet_conv_desc* d, const double* span, int kpa
     const bool plain = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1;
     const bool s2d = d->kh == 6 && d->kw == 6 && d->stride == 2 && d->pad == 2 && d->nseg == 1 && (d->H % 2) == 0 && (d->W % 2) == 0;
     if (!plain && !s2d) return 0;
-    if (d->Cout < 64 || (d->Wo % TW) != 0) return 0;
+    if (d->Cout < 64 || (d->Wo % 8) != 0) return 0;
+    const int mc = (d->Wo % 16) == 0 ? 16 : 8, th = 8 * (16 / mc);
     int ctot = 0;
     for (int s = 0; s < d->nseg; ++s) {
         if (d->in[s].shift != 0 || span[s] >= 2147483648.0) return 0;
@@ -422,8 +432,9 @@ int ccnet_conv2d_patch_try(const ccnet_conv_desc* d, const double* span, int kpa
     p.C0 = d->nseg == 2 ? d->in[0].C : p.Ctot;
     p.Hv = d->Ho; p.Wv = d->Wo; p.Hin = d->H; p.Win = d->W;
     p.Cout = d->Cout;
-    p.tiles_x = (d->Wo + TW - 1) / TW;
-    p.tiles_y = (d->Ho + TH - 1) / TH;
+    p.mc = mc;
+    p.tiles_x = (d->Wo + mc - 1) / mc;
+    p.tiles_y = (d->Ho + th - 1) / th;
     p.ntiles = (unsigned)((long long)d->B * p.tiles_x * p.tiles_y);
     p.weight = (const unsigned char*)d->weight;
     p.Kpad = kpad;

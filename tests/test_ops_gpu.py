@@ -66,6 +66,10 @@ CONV_CASES = [
     (256, 80, 3, 1, 1, 5, 16, "relu", True),
     (64, 128, 6, 2, 2, 32, 64, "silu", False),
     (128, 64, 6, 2, 2, 20, 32, "none", True),
+    # widths % 16 == 8: the 16 x 8 tile geometry of the patch kernel
+    (128, 128, 3, 1, 1, 20, 40, "silu", True),
+    (64, 96, 3, 1, 1, 33, 24, "silu", False),
+    (64, 64, 6, 2, 2, 48, 80, "silu", False),
 ]
 
 
