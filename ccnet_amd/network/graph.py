@@ -126,7 +126,7 @@ def declare(root, kind, depth, width, num_classes):
     if c["s2d"]:
         d.base_conv("stem.conv", 12, bc, 3)
     elif kind == "net_old":
-        d.base_conv("stem", 3, bc, 3, 2)  # reserved; net_old is not built yet
+        d.base_conv("stem.0", 3, bc, 3, 2)  # nn.Sequential(BaseConv(3, bc, 3, 2)), network/net_old.py:41-43
     else:
         d.module("stem.conv", nn.Conv2d(3, bc, 6, 2, 2, bias=False))
         d.bn("stem.bn", bc)
@@ -472,6 +472,12 @@ class Compiler:
         if c["s2d"]:
             w, b = self.folded("stem.conv")
             w6, stem_act = ops.s2d_to_6x6(w), self.act
+        elif c["kind"] == "net_old":
+            # 3x3 stride-2 pad-1 == the centre taps 1..3 of a 6x6 stride-2 pad-2 window (input offsets -1..+1)
+            w, b = self.folded("stem.0")
+            w6 = torch.zeros(w.shape[0], w.shape[1], 6, 6, dtype=w.dtype)
+            w6[:, :, 1:4, 1:4] = w
+            stem_act = self.act
         else:
             w6, b = ops.fold_bn(self.sd["stem.conv.weight"], self._bn("stem.bn"))
             stem_act = "silu"  # FocusReplaceConv is built without `act` (net_deploy.py:41)

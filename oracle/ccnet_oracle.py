@@ -224,7 +224,7 @@ def _up(x):
 
 # ----------------------------------------------------------------------------- the four nets
 def forward(kind, sd, x, depth=1.0, width=1.0, act="silu", taps=None):
-    """kind in {"net","net_deploy","net_amff","net_small_target"}.  Returns the list of raw head maps
+    """kind in {"net","net_deploy","net_amff","net_small_target","net_old"}.  Returns the list of raw head maps
     (B, 5+nc, H_k, W_k).  `taps`, if a dict, receives named intermediate tensors."""
     a = activation(act)
     bd = max(round(depth * 3), 1)
@@ -244,6 +244,16 @@ def forward(kind, sd, x, depth=1.0, width=1.0, act="silu", taps=None):
             l2 = tap("dark3", csp(sd, "dark3.1", s2d_conv(sd, "dark3.0", l1, a), bd, True, a))
             l3 = tap("dark4", csp(sd, "dark4.1", s2d_conv(sd, "dark4.0", l2, a), bd * 3, True, a))
             t = s2d_conv(sd, "dark5.0", l3, a)
+            t = tap("sppf", sppf(sd, "dark5.1", t, a))
+            t = tap("mobilevit", mobilevit(sd, "dark5.2", t))
+            l4 = tap("dark5", csp(sd, "dark5.3", t, bd, False, a))
+        elif kind == "net_old":
+            # network/net_old.py:41-93: plain stride-2 BaseConvs instead of SpaceToDepth, dark3 with 3*base_depth blocks
+            l0 = tap("stem", conv_bn_act(sd, "stem.0", x, 2, a))
+            l1 = tap("dark2", csp(sd, "dark2.1", conv_bn_act(sd, "dark2.0", l0, 2, a), bd, True, a))
+            l2 = tap("dark3", csp(sd, "dark3.1", conv_bn_act(sd, "dark3.0", l1, 2, a), bd * 3, True, a))
+            l3 = tap("dark4", csp(sd, "dark4.1", conv_bn_act(sd, "dark4.0", l2, 2, a), bd * 3, True, a))
+            t = conv_bn_act(sd, "dark5.0", l3, 2, a)
             t = tap("sppf", sppf(sd, "dark5.1", t, a))
             t = tap("mobilevit", mobilevit(sd, "dark5.2", t))
             l4 = tap("dark5", csp(sd, "dark5.3", t, bd, False, a))

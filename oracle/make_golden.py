@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 from ccnet_amd import synth  # noqa: E402
 from oracle import ccnet_oracle as orc  # noqa: E402
 
-KINDS = ("net", "net_deploy", "net_amff", "net_small_target")
+KINDS = ("net", "net_deploy", "net_amff", "net_small_target", "net_old")
 DEPTH, WIDTH, NC = 0.33, 0.5, 6
 
 
