@@ -170,3 +170,30 @@ def test_full_size_batch_independence_net_deploy():
         torch.cuda.synchronize()
         for lvl, (a, b) in enumerate(zip(big, one)):
             assert torch.equal(a[i:i + 1], b), "image %d level %d differs between bs%d and bs1" % (i, lvl, B)
+
+
+@pytest.mark.parametrize("kind,depth,width,nc,act,size", [
+    ("net", 1.0, 1.0, 80, "silu", 96),          # constructor defaults (l size, 80 classes): d_model 512 -> per-op Transformer path
+    ("net_deploy", 0.67, 0.75, 20, "relu", 128),  # m size, ReLU epilogues
+    ("net_amff", 0.33, 0.5, 6, "lrelu", 96),
+    ("net_small_target", 0.33, 0.25, 3, "relu6", 128),  # nano width: 16-channel layers, unaligned concat segments
+])
+def test_other_presets_and_activations_match_oracle(kind, depth, width, nc, act, size):
+    """every preset of utils/initialization.py:53-54 and every activation of model_block.py:24-31.
+    fp32 HIP path against the oracle (itself pinned to the reference on the s-size fixtures) on the same hash weights;
+    BN statistics are the hash generator's uncalibrated ones, so only relative agreement is asserted."""
+    from ccnet_amd import synth
+    from oracle import ccnet_oracle as orc
+    net = importlib.import_module("ccnet_amd.network." + kind).Net(depth, width, nc, act)
+    sd = synth.synth_state_dict(net.state_dict(), seed=2)
+    net.load_state_dict(sd)
+    net = net.to("cuda").eval().set_precision("fp32")
+    x = synth.synth_images(1, size, size, seed=4)
+    ref = orc.forward(kind, sd, x, depth, width, act)
+    outs = net(x.to("cuda"))
+    torch.cuda.synchronize()
+    assert len(outs) == len(ref)
+    for k, (o, r) in enumerate(zip(outs, ref)):
+        assert o.shape == r.shape
+        err = float((o.float().cpu() - r).abs().max() / r.abs().max().clamp_min(1e-30))
+        assert err < 1e-3, "level %d: rel err %.2e (ref max %.3g)" % (k, err, float(r.abs().max()))
