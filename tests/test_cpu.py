@@ -316,3 +316,24 @@ def test_socket_inference_surface(tmp_path):
     import inspect
     assert list(inspect.signature(s2s.inference).parameters)[:7] == ["model_name", "model_path", "dataset", "input_shape", "conf_thres",
                                                                       "nms_thres", "image_paths"]
+
+
+def test_eval_dirs_match_reference_get_map(tmp_path):
+    """tools/eval.py file round trip: the golden get_map cases written as ground_truth/ and detection_results/ txt files
+    and scored through ccnet_amd.tools.eval.map_from_dirs reproduce the reference's numbers."""
+    import json
+    from ccnet_amd.tools import eval as ceval
+    with open(os.path.join(GOLD, "map_case.json")) as f:
+        case = json.load(f)["get_map"][0]
+    names = ["cls0", "cls1", "cls2"]
+    (tmp_path / "gt").mkdir(); (tmp_path / "dr").mkdir()
+    for i, (g, d) in enumerate(zip(case["gt"], case["dets"])):
+        with open(tmp_path / "gt" / ("img%03d.txt" % i), "w") as f:
+            for c, l, t, r, b in g:
+                f.write("cls%d %d %d %d %d\n" % (c, l, t, r, b))
+        with open(tmp_path / "dr" / ("img%03d.txt" % i), "w") as f:
+            for c, conf, l, t, r, b in d:
+                f.write("cls%d %s %d %d %d %d\n" % (c, str(conf)[:6], l, t, r, b))
+    got = ceval.map_from_dirs(str(tmp_path / "gt"), str(tmp_path / "dr"), names, case["thresholds"])
+    for thr, ref in zip(case["thresholds"], case["map"]):
+        assert abs(got[thr] - ref) < 1e-12

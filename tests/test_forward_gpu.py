@@ -197,3 +197,21 @@ def test_other_presets_and_activations_match_oracle(kind, depth, width, nc, act,
         assert o.shape == r.shape
         err = float((o.float().cpu() - r).abs().max() / r.abs().max().clamp_min(1e-30))
         assert err < 1e-3, "level %d: rel err %.2e (ref max %.3g)" % (k, err, float(r.abs().max()))
+
+
+def test_evaluate_writes_reference_txt_format(tmp_path):
+    """tools/eval.py:81-103: one txt per image, `class conf[:6] left top right bottom` with integer pixels."""
+    from ccnet_amd import synth
+    from ccnet_amd.tools import eval as ceval
+    net = _model("net_deploy", 0.33, 0.5, 6, "bf16")
+    x = synth.synth_images(2, 224, 224, seed=0).numpy()
+    loader = [(x, None, [["a.jpg", 300, 200], ["b.png", 224, 224]])]
+    names = ["c%d" % i for i in range(6)]
+    ceval.evaluate(net, loader, [224, 224], 6, "cuda", str(tmp_path), names, conf_thres=0.3, nms_thres=0.6)
+    for stem in ("a", "b"):
+        lines = open(tmp_path / (stem + ".txt")).read().splitlines()
+        assert len(lines) > 0
+        for ln in lines:
+            parts = ln.split()
+            assert len(parts) == 6 and parts[0] in names and len(parts[1]) <= 6 and 0.0 <= float(parts[1]) <= 1.0
+            assert all(p.lstrip("-").isdigit() for p in parts[2:])
