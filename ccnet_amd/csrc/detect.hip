@@ -197,7 +197,8 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const int* counts, int np,
 __global__ __launch_bounds__(256) void nms_sweep_kernel(const int* counts, int np, int W, const unsigned long long* mask, const int* order, int nmax,
                                                         int* keep_idx, int* nkeep) {
     extern __shared__ unsigned long long removed[];  // [W]
-    __shared__ unsigned long long kept_s;
+    __shared__ int kept_l[64];  // positions (0..63) of the boxes kept in the current chunk
+    __shared__ int kept_n;
     const int b = blockIdx.x, t = threadIdx.x;
     const int n = counts[b];
     const int nw = (n + 63) / 64;
@@ -225,19 +226,31 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const int* counts, int n
                 keep_idx[(size_t)b * nmax + pos] = ob[i];
             }
             total += __popcll(kept);
-            if (t == 0) kept_s = kept;
+            if ((kept >> t) & 1ull) kept_l[__popcll(kept & ((1ull << t) - 1ull))] = t;
+            if (t == 0) kept_n = __popcll(kept);
         }
         __syncthreads();
-        const unsigned long long kept = kept_s;
-        for (int w = c + 1 + t; w < nw; w += 256) {
-            unsigned long long acc = removed[w];
-            unsigned long long k = kept;
-            while (k) {
-                const int j = __ffsll((long long)k) - 1;
-                k &= k - 1;
-                acc |= mb[(size_t)(c * 64 + j) * W + w];
+        // OR the mask rows of the kept boxes into the words still ahead.  The loads are what costs (L2 round trips), so
+        // they are spread over the whole block -- wave q takes every fourth kept row -- and issued 8 at a time; rows are
+        // picked with a clamped index (a repeated OR is harmless), so no load sits behind a branch.
+        const int nk = kept_n;
+        if (nk > 0) {
+            const int wave = t >> 6, lane = t & 63;
+            const int mine = (nk - wave + 3) / 4;  // kept rows wave, wave+4, ...
+            for (int w = c + 1 + lane; w < nw; w += 64) {
+                unsigned long long acc = 0ull;
+                for (int q = 0; q < mine; q += 8) {
+                    unsigned long long v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = wave + 4 * min(q + u, mine - 1);
+                        v[u] = mb[(size_t)(c * 64 + kept_l[idx]) * W + w];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc |= v[u];
+                }
+                if (mine > 0 && acc) atomicOr(&removed[w], acc);
             }
-            removed[w] = acc;
         }
         __syncthreads();
     }
