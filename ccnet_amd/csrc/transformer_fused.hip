@@ -209,11 +209,11 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
     };
 
     // acc (+ bias + residual from X) -> Z
-    auto to_z = [&](f32x4 (&acc)[4][2], const float* bias) __attribute__((always_inline)) {
+    auto to_z = [&](f32x4 (&acc)[4][2], const float4 (&bias2)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n0 = wave * 32 + j * 16 + fq * 4;
-            const float4 bv = *(const float4*)(bias + n0);
+            const float4 bv = bias2[j];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int row = mt * 16 + fr;
@@ -238,12 +238,14 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
             // projections of this head: wave w produces columns [16w, 16w+16) of Q_h, K_h and V_h
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
+                // biases are fetched BEFORE the GEMM: vector-memory results return in issue order, so a load issued after
+                // it would sit behind the 16 weight fragments the ring has in flight
+                const int c0 = wave * 16 + fq * 4;  // column inside the head
+                const float4 bv = *(const float4*)(in_bias + part * E + h * HD + c0);
                 f32x4 acc[4][1];
                 zero<1>(acc);
                 mm256<1>(acc, part == 0 ? XQ : XKV, ring, wp, loff, lx, ((h * 3 + part) * 8) % RING); TS(0); TPH(1);
                 unsigned short* dstT = part == 0 ? Qs : part == 1 ? Ks : Vs;
-                const int c0 = wave * 16 + fq * 4;  // column inside the head
-                const float4 bv = *(const float4*)(in_bias + part * E + h * HD + c0);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     float v[4] = {acc[mt][0][0] + bv.x, acc[mt][0][1] + bv.y, acc[mt][0][2] + bv.z, acc[mt][0][3] + bv.w};
@@ -323,10 +325,13 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
             }
             TSYNC();  // every wave is done with this head's K/V (and AO is complete after the second head)
         }
+        float4 ob[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ob[j] = *(const float4*)(out_bias + wave * 32 + j * 16 + fq * 4);
         f32x4 acc[4][2];
         zero<2>(acc);
         mm256<2>(acc, AO, ring, wp, loff, lx); TS(0); TPH(1);
-        to_z(acc, out_bias);
+        to_z(acc, ob);
         TSYNC();
     };
 
@@ -334,16 +339,22 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
         const float* b1 = pp;
         const float* b2 = pp + FF;
         pp += FF + E;
+        float4 b2v[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b2v[j] = *(const float4*)(b2 + wave * 32 + j * 16 + fq * 4);
         f32x4 acc2[4][2];
         zero<2>(acc2);
         for (int c = 0; c < FF / 256; ++c) {
+            float4 hb[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) hb[j] = *(const float4*)(b1 + c * 256 + wave * 32 + j * 16 + fq * 4);
             f32x4 acc1[4][2];
             zero<2>(acc1);
             mm256<2>(acc1, X, ring, wp, loff, lx); TS(0); TPH(1);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n0 = wave * 32 + j * 16 + fq * 4;  // column inside the chunk
-                const float4 bv = *(const float4*)(b1 + c * 256 + n0);
+                const float4 bv = hb[j];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     float v[4] = {fmaxf(acc1[mt][j][0] + bv.x, 0.f), fmaxf(acc1[mt][j][1] + bv.y, 0.f), fmaxf(acc1[mt][j][2] + bv.z, 0.f),
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
             mm256<2>(acc2, Tb, ring, wp, loff, lx); TS(0); TPH(1);
             TSYNC();  // before the next chunk (or Z) overwrites the hidden tile
         }
-        to_z(acc2, b2);
+        to_z(acc2, b2v);
         TSYNC();
     };
     auto add_ln = [&](unsigned char* dst, bool from_x, bool to_global) __attribute__((always_inline)) {
