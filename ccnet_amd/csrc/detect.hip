@@ -23,24 +23,27 @@ struct DecodeP {
     float* out;
 };
 
+// one thread per output ELEMENT (b, anchor, channel): with NHWC heads both the load and the store of a wave are contiguous
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeP p) {
-    long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)p.B * p.A) return;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)p.B * p.A * p.nch) return;
+    const long long idx = e / p.nch;
+    const int c = (int)(e - idx * p.nch);
     const int a = (int)(idx % p.A), b = (int)(idx / p.A);
     int l = 0;
     while (l + 1 < p.nlev && a >= p.a0[l + 1]) ++l;
     const int r = a - p.a0[l];
     const int gy = r / p.w[l], gx = r - gy * p.w[l];
-    const float* src = p.head[l] + (long long)b * p.sb[l] + (long long)r * p.sp[l];
-    float* dst = p.out + idx * p.nch;
+    const float raw = p.head[l][(long long)b * p.sb[l] + (long long)r * p.sp[l] + (long long)c * p.sc[l]];
     const float s = p.stride[l];
-    const long long sc = p.sc[l];
     // ((raw + grid) * stride) / dim, exp(raw) * stride / dim: same op order as bbox.py:70-76
-    dst[0] = ((src[0] + (float)gx) * s) / p.in_w;
-    dst[1] = ((src[sc] + (float)gy) * s) / p.in_h;
-    dst[2] = (expf(src[2 * sc]) * s) / p.in_w;
-    dst[3] = (expf(src[3 * sc]) * s) / p.in_h;
-    for (int c = 4; c < p.nch; ++c) dst[c] = 1.0f / (1.0f + expf(-src[c * sc]));
+    float v;
+    if (c == 0) v = ((raw + (float)gx) * s) / p.in_w;
+    else if (c == 1) v = ((raw + (float)gy) * s) / p.in_h;
+    else if (c == 2) v = (expf(raw) * s) / p.in_w;
+    else if (c == 3) v = (expf(raw) * s) / p.in_h;
+    else v = 1.0f / (1.0f + expf(-raw));
+    p.out[e] = v;
 }
 
 // ---- filter: one block (1024 threads) per image, anchors in order, stable compaction
@@ -295,7 +298,8 @@ extern "C" int ccnet_decode(const float* const* head_dev, const int64_t* sb, con
     }
     p.a0[nlev] = A;
     p.nlev = nlev; p.B = B; p.A = A; p.nch = 5 + nc; p.in_h = in_h; p.in_w = in_w; p.out = out_dev;
-    const unsigned blocks = (unsigned)(((long long)B * A + 255) / 256);
+    CC_REQUIRE((double)B * A * (5 + nc) < 4.0e11, "decode: too many elements");
+    const unsigned blocks = (unsigned)(((long long)B * A * (5 + nc) + 255) / 256);
     return ccnet_submit(
         [p, blocks](hipStream_t st, const float*) -> int {
             hipLaunchKernelGGL(decode_kernel, dim3(blocks), dim3(256), 0, st, p);

@@ -47,7 +47,7 @@ def _filter_and_nms(pred, num_classes, conf_thres, nms_thres, image_hw):
     cand = torch.empty(B, A, 7, dtype=torch.float32, device=dev)
     counts = torch.empty(B, dtype=torch.int32, device=dev)
     ops.filter_candidates(pred, num_classes, conf_thres, cand, counts)
-    nmax = int(counts.max().item())  # the one sync
+    nmax = int(counts.cpu().max())  # the one sync (a B-int copy; the maximum is taken on the host)
     nmax = max(nmax, 1)
     return (cand, counts) + _nms(cand, counts, nmax, nms_thres, image_hw)
 
@@ -70,7 +70,7 @@ def nms_keep_indices(cand, counts, nms_thres):
     _require_cuda(cand, "nms_keep_indices")
     B = cand.shape[0]
     cand = cand.float().contiguous()
-    nmax = max(int(counts.max().item()), 1) if counts.numel() else 1
+    nmax = max(int(counts.cpu().max()), 1) if counts.numel() else 1
     hw = torch.ones(B, 2, dtype=torch.int32, device=cand.device)
     det, keep_idx, nkeep = _nms(cand, counts.to(torch.int32).contiguous(), nmax, nms_thres, hw)
     nk = nkeep.cpu().numpy()
