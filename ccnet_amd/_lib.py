@@ -59,6 +59,13 @@ def lib():
         L.ccnet_nms_workspace_bytes.argtypes = [i32, i32]
         L.ccnet_nms_workspace_bytes.restype = sz
         L.ccnet_nms.argtypes = [vp, vp, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp]
+        ll = C.c_longlong
+        L.ccnet_resample_ksize.argtypes = [i32, i32]
+        L.ccnet_resample_coeffs.argtypes = [i32, i32, vp, vp, i32]
+        L.ccnet_preprocess_workspace_bytes.argtypes = [i32, i32, i32]
+        L.ccnet_preprocess_workspace_bytes.restype = sz
+        L.ccnet_preprocess.argtypes = [vp, i32, i32, i32, i32, ll, ll, i32, vp, i32, i32, ll, ll, i32, i32, i32, i32,
+                                       vp, vp, i32, vp, vp, i32, vp, i32, vp, sz, vp]
         L.ccnet_plan_begin.argtypes = [C.POINTER(vp)]
         L.ccnet_plan_end.argtypes = []
         L.ccnet_plan_num_ops.argtypes = [vp]

@@ -158,6 +158,33 @@ int ccnet_nms(const float* cand_dev, const int32_t* counts_dev, int B, int A, in
               const int32_t* image_hw_dev, float* det_dev, int32_t* keep_idx_dev, int32_t* nkeep_dev, void* workspace_dev,
               ccnet_stream stream);
 
+/* ---- image preparation in front of the path (SURVEY.md §8(f)1) ----------------------------------------------
+ * Replaces tools/eval.py:134-140 (`image.resize((W, H), Image.BICUBIC)`, float32, /255, mean/std, HWC->CHW) and the
+ * letterbox of utils/datasets.py:123-134 (+ :73-77).  The resize is Pillow's ImagingResample for 8-bit images (third
+ * party; src/libImaging/Resample.c): integer arithmetic, results are bit-exact.  The cv2.INTER_CUBIC flavour of
+ * tools/demo.py:53 is a different filter and is not provided.
+ *
+ * ccnet_resample_ksize: taps per output pixel of one axis (negative CCNET_E* on bad sizes).
+ * ccnet_resample_coeffs (host only, no GPU needed): Resample.c's precompute_coeffs + normalize_coeffs_8bpc for the full
+ * box; bounds[out_size][2] = (first source index, tap count), kk[out_size][ksize] 22-bit fixed-point weights. */
+int ccnet_resample_ksize(int in_size, int out_size);
+int ccnet_resample_coeffs(int in_size, int out_size, int32_t* bounds_host, int32_t* kk_host, int ksize);
+/* ccnet_preprocess: n images of one size.  src_dev: uint8, pixel (i,y,x) channel c at
+ * src_dev[i*src_image_stride + y*src_row_stride + x*src_pixel_stride + c], channels 3 (RGB) or 1 (grey, replicated like
+ * convert("RGB")).  Each image is resized to nw x nh, pasted at (dx, dy) on an H x W canvas of value `fill` (the plain
+ * resize of eval.py is dx = dy = 0, nw = W, nh = H), every 8-bit value v of channel c becomes lut_dev[c*256 + v] (the host
+ * fills the table with the reference's numpy arithmetic) and is written to
+ * out_dev[i*out_image_stride + c*out_chan_stride + y*W + x] (fp32).  h*/v* tables: device copies of
+ * ccnet_resample_coeffs(iw, nw) and (ih, nh).  workspace_dev: ccnet_preprocess_workspace_bytes(n, ih, nw) bytes, 16-byte
+ * aligned (the 8-bit intermediate image between the two passes). */
+size_t ccnet_preprocess_workspace_bytes(int n, int ih, int nw);
+int ccnet_preprocess(const uint8_t* src_dev, int n, int ih, int iw, int channels, long long src_image_stride,
+                     long long src_row_stride, int src_pixel_stride, float* out_dev, int H, int W,
+                     long long out_image_stride, long long out_chan_stride, int dx, int dy, int nw, int nh,
+                     const int32_t* hbounds_dev, const int32_t* hk_dev, int hks, const int32_t* vbounds_dev,
+                     const int32_t* vk_dev, int vks, const float* lut_dev, int fill, void* workspace_dev,
+                     size_t workspace_bytes, ccnet_stream stream);
+
 /* ---- plan: a recorded sequence of the calls above, replayed with one C call per forward --------------------
  * Replaces the Python-level op-by-op dispatch of Net.forward (network/net.py:194-275 and siblings).
  * Recording: ccnet_plan_begin(&plan) makes the CALLING THREAD record instead of launch until ccnet_plan_end();

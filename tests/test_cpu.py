@@ -337,3 +337,63 @@ def test_eval_dirs_match_reference_get_map(tmp_path):
     got = ceval.map_from_dirs(str(tmp_path / "gt"), str(tmp_path / "dr"), names, case["thresholds"])
     for thr, ref in zip(case["thresholds"], case["map"]):
         assert abs(got[thr] - ref) < 1e-12
+
+
+# ----------------------------------------------------------------------------- image preparation
+def _prep_cases():
+    z = np.load(os.path.join(GOLD, "preprocess_cases.npz"))
+    names = sorted({k.rsplit("/", 1)[0] for k in z.files})
+    return [(n, z[n + "/src"], tuple(int(v) for v in z[n + "/input_shape"]), z[n + "/out"]) for n in names]
+
+
+def test_preprocess_oracle_matches_reference_fixture():
+    """Fixtures come from the reference's own evaluate_one_img / Datasets.__getitem__ (oracle/make_golden_preprocess.py)."""
+    from oracle import preprocess_oracle as po
+    cases = _prep_cases()
+    assert len(cases) == 8
+    for name, src, shape, exp in cases:
+        if src.ndim == 2:
+            src = np.repeat(src[..., None], 3, 2)  # convert("RGB") of a grey image replicates the channel
+        got = (po.preprocess_eval if name.startswith("eval/") else po.preprocess_letterbox)(src, shape)
+        assert got.dtype == np.float32 and np.array_equal(got, exp), name
+
+
+def test_preprocess_oracle_matches_pillow_live():
+    """The resize is Pillow's; where Pillow is importable the restatement is checked against it on random sizes (bit-exact)."""
+    Image = pytest.importorskip("PIL.Image")
+    from oracle import preprocess_oracle as po
+    rng = np.random.default_rng(1)
+    for t in range(25):
+        ih, iw = (int(v) for v in rng.integers(1, 200, 2))
+        oh, ow = (int(v) for v in rng.integers(1, 260, 2))
+        if t % 5 == 0:
+            ow = iw
+        img = rng.integers(0, 256, (ih, iw, 3), dtype=np.uint8)
+        ref = np.array(Image.fromarray(img, "RGB").resize((ow, oh), Image.BICUBIC))
+        assert np.array_equal(po.resize_bicubic_u8(img, ow, oh), ref), (ih, iw, oh, ow)
+
+
+def test_resample_tables_of_the_library_match_oracle():
+    """ccnet_resample_coeffs is host code (no GPU): its tables must equal the oracle's for up-, down- and same-size axes."""
+    from ccnet_amd.utils import preprocess as pp
+    from oracle import preprocess_oracle as po
+    for in_size, out_size in [(200, 224), (200, 640), (1080, 640), (1920, 640), (97, 64), (50, 64), (7, 7), (1, 5), (5, 1), (3000, 17), (640, 1280)]:
+        b, k = pp.resample_tables(in_size, out_size)
+        ob, ok, oks = po.precompute_coeffs(in_size, out_size)
+        assert k.shape[1] == oks and np.array_equal(b, ob) and np.array_equal(k, ok), (in_size, out_size)
+        assert (b[:, 0] >= 0).all() and (b[:, 0] + b[:, 1] <= in_size).all() and (b[:, 1] <= oks).all()
+    with pytest.raises(RuntimeError):
+        pp.resample_tables(0, 5)
+    with pytest.raises(RuntimeError):
+        pp.resample_tables(10 ** 6, 1)  # more taps than the library supports
+
+
+def test_normalisation_lut_and_letterbox_geometry():
+    from ccnet_amd.utils import preprocess as pp
+    from oracle import preprocess_oracle as po
+    lut = pp.normalisation_lut()
+    assert lut.shape == (3, 256) and lut.dtype == np.float32
+    img = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, 2)
+    assert np.array_equal(po.normalise(img)[:, 0, :], lut)
+    for iw, ih, shape in [(120, 80, (96, 96)), (60, 150, (64, 96)), (48, 48, (96, 96)), (200, 200, (640, 640)), (1920, 1080, (640, 640)), (333, 77, (224, 224))]:
+        assert pp.letterbox_geometry(iw, ih, shape) == po.letterbox_geometry(iw, ih, shape)
