@@ -1,5 +1,6 @@
 """tools/eval.py of the reference, tensor side on libccnet_hip: `evaluate` (eval.py:48-104) writes one detection-result
-txt per image in the format utils/map.py reads (`class conf[:6] left top right bottom`, integer-truncated pixels), and
+txt per image in the format utils/map.py reads (`class conf[:6] left top right bottom`, integer-truncated pixels),
+`evaluate_one_img` (eval.py:107-170) does the same from image files with the resize and normalisation on the GPU, and
 `map_from_dirs` scores such a directory against a ground-truth directory with the restated arithmetic of
 ccnet_amd/utils/map.py (the reference's get_map, utils/map.py:307-841, minus its plotting)."""
 import glob
@@ -28,12 +29,45 @@ def evaluate(model, val_dataloader, input_shape, num_classes, device, save_box_p
             with open(os.path.join(save_box_path, file_name + ".txt"), "w") as f:
                 if output is None:
                     return
-                label = np.array(output[:, 6], dtype="int32")
-                conf = output[:, 4] * output[:, 5]
-                for j, c in enumerate(label):
-                    top, left, bottom, right = output[j, :4]
-                    f.write("%s %s %s %s %s %s\n" % (class_names[int(c)], str(conf[j])[:6], str(int(left)), str(int(top)), str(int(right)),
-                                                     str(int(bottom))))
+                _write_rows(f, output, class_names)
+
+
+def _write_rows(f, output, class_names):
+    label = np.array(output[:, 6], dtype="int32")
+    conf = output[:, 4] * output[:, 5]
+    for j, c in enumerate(label):
+        top, left, bottom, right = output[j, :4]
+        f.write("%s %s %s %s %s %s\n" % (class_names[int(c)], str(conf[j])[:6], str(int(left)), str(int(top)), str(int(right)), str(int(bottom))))
+
+
+def evaluate_one_img(model, val_lines, input_shape, num_classes, device, data_path, save_box_path, class_names, conf_thres=0.001, nms_thres=0.6,
+                     batch_size=1):
+    """tools/eval.py:107-178: each line of val_lines names a file under <data_path>/JPEGImages; the file is decoded on the
+    host (PIL, `convert("RGB")`, :129-134) and everything after that -- bicubic resize, normalisation, CHW (:135-140),
+    forward, decode, post_process -- runs on the GPU (ccnet_amd/utils/preprocess.py).  batch_size > 1 groups images per
+    forward; keep 1 for `network.net.Net` when results must equal the reference's image-at-a-time run (its Transformer
+    attends over the batch axis)."""
+    from PIL import Image
+
+    from ..utils.preprocess import preprocess
+    os.makedirs(save_box_path, exist_ok=True)
+    model.eval()
+    names = [line.split()[0] for line in val_lines]
+    for s in range(0, len(names), max(1, int(batch_size))):
+        chunk = names[s:s + max(1, int(batch_size))]
+        images = []
+        for name in chunk:
+            with Image.open("%s/JPEGImages/%s" % (data_path, name)) as im:
+                images.append(np.asarray(im.convert("RGB")))
+        with torch.no_grad():
+            x, image_info = preprocess(images, input_shape, device)
+            outputs = decode_outputs(model(x), input_shape)
+            results = post_process(outputs, num_classes, input_shape, image_info, conf_thres=conf_thres, nms_thres=nms_thres)
+        for name, output in zip(chunk, results):
+            with open(os.path.join(save_box_path, os.path.splitext(name)[0] + ".txt"), "w") as f:
+                if output is None:
+                    return
+                _write_rows(f, output, class_names)
 
 
 def _read_dir(path, class_names, with_conf):

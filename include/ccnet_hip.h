@@ -174,7 +174,7 @@ int ccnet_resample_coeffs(int in_size, int out_size, int32_t* bounds_host, int32
  * convert("RGB")).  Each image is resized to nw x nh, pasted at (dx, dy) on an H x W canvas of value `fill` (the plain
  * resize of eval.py is dx = dy = 0, nw = W, nh = H), every 8-bit value v of channel c becomes lut_dev[c*256 + v] (the host
  * fills the table with the reference's numpy arithmetic) and is written to
- * out_dev[i*out_image_stride + c*out_chan_stride + y*W + x] (fp32).  h*/v* tables: device copies of
+ * out_dev[i*out_image_stride + c*out_chan_stride + y*W + x] (fp32).  The hbounds/hk and vbounds/vk tables are device copies of
  * ccnet_resample_coeffs(iw, nw) and (ih, nh).  workspace_dev: ccnet_preprocess_workspace_bytes(n, ih, nw) bytes, 16-byte
  * aligned (the 8-bit intermediate image between the two passes). */
 size_t ccnet_preprocess_workspace_bytes(int n, int ih, int nw);

@@ -215,3 +215,40 @@ def test_evaluate_writes_reference_txt_format(tmp_path):
             parts = ln.split()
             assert len(parts) == 6 and parts[0] in names and len(parts[1]) <= 6 and 0.0 <= float(parts[1]) <= 1.0
             assert all(p.lstrip("-").isdigit() for p in parts[2:])
+
+
+def test_evaluate_one_img_from_files_equals_host_prepared_input(tmp_path):
+    """tools/eval.py:107-170 from image files: the GPU-prepared input is bit-identical to the oracle's restatement of
+    eval.py:134-140, so the detection files must be identical to those of `evaluate` fed with host-prepared arrays."""
+    Image = pytest.importorskip("PIL.Image")
+    from ccnet_amd.tools import eval as ceval
+    from oracle import preprocess_oracle as po
+    rng = np.random.default_rng(3)
+    net = _model("net_deploy", 0.33, 0.5, 6, "fp32")
+    names = ["c%d" % i for i in range(6)]
+    os.makedirs(tmp_path / "JPEGImages")
+    srcs = {"a.png": rng.integers(0, 256, (200, 200, 3), dtype=np.uint8), "b.png": rng.integers(0, 256, (120, 260, 3), dtype=np.uint8),
+            "g.png": rng.integers(0, 256, (90, 70), dtype=np.uint8)}
+    for fn, arr in srcs.items():
+        Image.fromarray(arr).save(tmp_path / "JPEGImages" / fn)
+    lines = [fn + " 1,2,3,4,0" for fn in srcs]
+    ceval.evaluate_one_img(net, lines, [224, 224], 6, "cuda", str(tmp_path), str(tmp_path / "dev"), names, conf_thres=0.3, nms_thres=0.6)
+    ceval.evaluate_one_img(net, lines, [224, 224], 6, "cuda", str(tmp_path), str(tmp_path / "dev3"), names, conf_thres=0.3, nms_thres=0.6, batch_size=3)
+    loader = []
+    for fn, arr in srcs.items():
+        rgb = arr if arr.ndim == 3 else np.repeat(arr[..., None], 3, 2)
+        loader.append((po.preprocess_eval(rgb, (224, 224))[None], None, [[fn, rgb.shape[1], rgb.shape[0]]]))
+    ceval.evaluate(net, loader, [224, 224], 6, "cuda", str(tmp_path / "host"), names, conf_thres=0.3, nms_thres=0.6)
+    total = 0
+    for fn in srcs:
+        stem = os.path.splitext(fn)[0] + ".txt"
+        host = open(tmp_path / "host" / stem).read()
+        assert open(tmp_path / "dev" / stem).read() == host
+        total += len(host.splitlines())
+    assert total > 0
+    # net_deploy is per-image independent, so grouping three images into one forward changes at most the last bits
+    for fn in srcs:
+        stem = os.path.splitext(fn)[0] + ".txt"
+        a = [ln.split()[0] for ln in open(tmp_path / "dev" / stem)]
+        b = [ln.split()[0] for ln in open(tmp_path / "dev3" / stem)]
+        assert len(a) == len(b)

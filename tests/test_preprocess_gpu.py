@@ -61,6 +61,10 @@ def test_preprocess_full_size_batch_and_downscale():
     big = rng.integers(0, 256, (2, 1080, 1920, 3), dtype=np.uint8)
     out, _ = pp.preprocess(torch.from_numpy(big), (640, 640), DEV)
     assert np.array_equal(out[1].cpu().numpy(), po.preprocess_eval(big[1], (640, 640)))
+    # a reduction too strong for the LDS-staged horizontal pass (707 taps per pixel): the direct kernel takes over
+    wide = rng.integers(0, 256, (1, 40, 3000, 3), dtype=np.uint8)
+    out, _ = pp.preprocess(torch.from_numpy(wide), (16, 17), DEV)
+    assert np.array_equal(out[0].cpu().numpy(), po.preprocess_eval(wide[0], (16, 17)))
     # constant image: every weight row sums to 2^22 up to rounding, so the value must survive both passes
     flat = np.full((1, 123, 77, 3), 201, np.uint8)
     out, _ = pp.preprocess(torch.from_numpy(flat), (640, 640), DEV, letterbox=True)
