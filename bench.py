@@ -206,6 +206,25 @@ def main():
                       "global_batch": world * B, "parallelism": "batch-sharded replicas x%d" % world,
                       "detections_last_step": int(sum(0 if d is None else d.shape[0] for d in dets))},
            "roofline": roofline}
+    if rank == 0 and world == 1:
+        # the step in front of the path, reported beside the headline and not part of `value`: B NEU-DET-sized
+        # 8-bit images resident in HBM -> the (B,3,S,S) fp32 batch (Pillow-exact bicubic + normalisation + CHW)
+        from ccnet_amd.utils import preprocess as pp
+        src = torch.randint(0, 256, (B, 200, 200, 3), dtype=torch.uint8, device=dev)
+        dst = torch.empty((B, 3, S, S), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            pp.preprocess_group(src, dst, (S, S))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            pp.preprocess_group(src, dst, (S, S))
+        e1.record()
+        torch.cuda.synchronize()
+        pms = e0.elapsed_time(e1) / 20
+        pbytes = B * (200 * 200 * 3 + 3 * S * S * 4)
+        out["preprocess"] = {"workload": "%d x 200x200x3 u8 -> %dx%d fp32 CHW, bicubic (Pillow-exact)" % (B, S, S), "ms": round(pms, 4),
+                             "bound": "hbm", "achieved": round(pbytes / pms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(pbytes / pms / 1e6 / HBM_PEAK_GBS, 4), "in_value": False}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.kind, S, args.conf, args.nms)
