@@ -38,6 +38,19 @@ struct ccnet_plan {
     std::vector<std::pair<int, const float*>> seen;  // (device, x) pairs that ran eagerly once (warm-up before capture)
     unsigned long long tick = 0;
     ~ccnet_plan() {
+        // a replay or side-lane work of this plan may still be running: let every device that holds one of its graphs or
+        // lane streams drain before they are destroyed (destruction is rare; forwards never come here)
+        int cur = 0;
+        const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+        std::vector<int> devs;
+        for (auto& g : graphs) devs.push_back(g.device);
+        for (auto& r : res) devs.push_back(r.device);
+        for (size_t i = 0; i < devs.size(); ++i) {
+            bool dup = false;
+            for (size_t j = 0; j < i; ++j) dup = dup || devs[j] == devs[i];
+            if (!dup && hipSetDevice(devs[i]) == hipSuccess) (void)hipDeviceSynchronize();
+        }
+        if (have_cur && !devs.empty()) (void)hipSetDevice(cur);
         for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
         for (auto& r : res) {
             for (int i = 0; i < MAX_LANES - 1; ++i)
@@ -256,11 +269,12 @@ extern "C" int ccnet_plan_run_timed(const ccnet_plan* plan, const float* x_dev, 
     CC_REQUIRE(plan != nullptr && ms_per_op != nullptr, "plan_run_timed: null argument");
     CC_REQUIRE(!plan->open, "plan_run_timed: plan is still being recorded");
     const size_t n = plan->ops.size();
-    std::vector<hipEvent_t> ev(n + 1);
-    for (auto& e : ev) CC_HIP(hipEventCreate(&e));
+    std::vector<hipEvent_t> ev(n + 1, nullptr);
     hipStream_t st = (hipStream_t)stream;
     int rc = CCNET_OK;
-    CC_HIP(hipEventRecord(ev[0], st));
+    for (auto& e : ev)
+        if (rc == CCNET_OK && hipEventCreate(&e) != hipSuccess) rc = ccnet_set_error(CCNET_EHIP, "hipEventCreate failed");
+    if (rc == CCNET_OK && hipEventRecord(ev[0], st) != hipSuccess) rc = ccnet_set_error(CCNET_EHIP, "hipEventRecord failed");
     for (size_t i = 0; i < n && rc == CCNET_OK; ++i) {
         if (plan->ops[i].wait_src < 0) rc = plan->ops[i].fn(st, x_dev);  // one stream, recorded order: waits are no-ops
         if (hipEventRecord(ev[i + 1], st) != hipSuccess) rc = ccnet_set_error(CCNET_EHIP, "hipEventRecord failed");
@@ -268,7 +282,8 @@ extern "C" int ccnet_plan_run_timed(const ccnet_plan* plan, const float* x_dev, 
     if (rc == CCNET_OK && hipStreamSynchronize(st) != hipSuccess) rc = ccnet_set_error(CCNET_EHIP, "hipStreamSynchronize failed");
     for (size_t i = 0; i < n && rc == CCNET_OK; ++i)
         if (hipEventElapsedTime(&ms_per_op[i], ev[i], ev[i + 1]) != hipSuccess) rc = ccnet_set_error(CCNET_EHIP, "hipEventElapsedTime failed");
-    for (auto& e : ev) (void)hipEventDestroy(e);
+    for (auto& e : ev)
+        if (e) (void)hipEventDestroy(e);
     return rc;
 }
 

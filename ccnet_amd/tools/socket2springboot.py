@@ -3,10 +3,13 @@
 Differences, all outside the tensor path: the model is built and its weights are loaded once per
 (model_path, num_classes, device) and kept (the reference rebuilds the model for every request, :58-61); `class_names`
 may be passed instead of being read from datasets/<dataset>/classes.txt; `images` may carry already decoded BGR arrays
-so that callers without OpenCV file access (and the tests) can use the entry point.  The socket server itself
-(:126-215) is control plane and is not rebuilt.
+so that callers without OpenCV file access (and the tests) can use the entry point.  The wire protocol of the server
+(:174-215: a JSON request terminated by "over", the reply `str(dict)`, "500" on any exception) is `handle_request`;
+`ServerThreading` / `main` (:126-172) are the same thin socket loop around it.
 """
+import json
 import os
+import socket
 import threading
 
 import numpy as np
@@ -66,3 +69,70 @@ def inference(model_name, model_path, dataset, input_shape, conf_thres, nms_thre
         results = predict(model, torch.from_numpy(data).to(device), num_classes, input_shape, image_info, conf_thres, nms_thres)
         msg["annotations"].extend(detections_to_annotations(results[0], image_id, class_names))
     return msg
+
+
+def _reply_text(res):
+    """str(dict) as the reference sends it (:210).  Its "conf" values are numpy float32 scalars, which numpy 1.x (the
+    reference's era) prints as their shortest decimal form; keep that text whatever numpy is installed."""
+    if not res:
+        return str(res)
+    anns = [dict(a, conf=float(str(np.float32(a["conf"])))) for a in res.get("annotations", [])]
+    return str({"image": res.get("image", []), "annotations": anns})
+
+
+def handle_request(msg, **kwargs):
+    """One request of the protocol (:181-213): `msg` is the received text ending in "over"; returns the reply text --
+    `str(result dict)`, or "500" when anything raises.  kwargs go to `inference` (class_names, images, device, ...)."""
+    try:
+        text = msg
+        if text.strip().endswith("over"):
+            text = text[:-4]  # :190 cuts exactly four characters, as received
+        req = json.loads(text)
+        image_paths = [p for p in req["image_path"]]
+        res = inference(req["model_name"], req["model_path"], req["dataset"], req["input_shape"], req["conf_thres"], req["nms_thres"], image_paths,
+                        **kwargs)
+        return _reply_text(res)
+    except Exception:
+        return "500"
+
+
+class ServerThreading(threading.Thread):
+    """:158-216: one thread per connection; reads until the text ends in "over", answers once, closes."""
+
+    def __init__(self, client_socket, address, recvsize=1024 * 1024, encoding="utf-8", **kwargs):
+        threading.Thread.__init__(self)
+        self._socket = client_socket
+        self._address = address
+        self._recvsize = recvsize
+        self._encoding = encoding
+        self._kwargs = kwargs
+
+    def run(self):
+        try:
+            msg = ""
+            while True:
+                rec = self._socket.recv(self._recvsize)
+                msg += rec.decode(self._encoding)
+                if msg.strip().endswith("over") or not rec:
+                    break
+            self._socket.send(handle_request(msg, **self._kwargs).encode(self._encoding))
+        except Exception:
+            try:
+                self._socket.send("500".encode(self._encoding))
+            except OSError:
+                pass
+        finally:
+            self._socket.close()
+
+
+def main(host=None, port=12345, **kwargs):
+    """:126-155.  Unlike the reference, models stay loaded between requests (`_model_for`)."""
+    server_socket = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    server_socket.bind((host if host is not None else socket.gethostname(), port))
+    server_socket.listen(5)
+    try:
+        while True:
+            client_socket, address = server_socket.accept()
+            ServerThreading(client_socket, address, **kwargs).start()
+    finally:
+        server_socket.close()

@@ -397,3 +397,33 @@ def test_normalisation_lut_and_letterbox_geometry():
     assert np.array_equal(po.normalise(img)[:, 0, :], lut)
     for iw, ih, shape in [(120, 80, (96, 96)), (60, 150, (64, 96)), (48, 48, (96, 96)), (200, 200, (640, 640)), (1920, 1080, (640, 640)), (333, 77, (224, 224))]:
         assert pp.letterbox_geometry(iw, ih, shape) == po.letterbox_geometry(iw, ih, shape)
+
+
+def test_socket_protocol_over_a_real_connection():
+    """tools/socket2springboot.py:174-215: text up to "over" is JSON; the reply is str(dict); any exception -> "500".
+    A model_name other than "Net" answers {} without touching a GPU, which is what this CPU test can exercise end to end."""
+    import json
+    import socket
+    from ccnet_amd.tools import socket2springboot as s2s
+    req = {"model_name": "Other", "model_path": "w.pth", "dataset": "NEUDET", "input_shape": [224, 224], "conf_thres": 0.5, "nms_thres": 0.6,
+           "image_path": ["a.jpg", "b.jpg"]}
+    assert s2s.handle_request(json.dumps(req) + "over") == "{}"
+    assert s2s.handle_request("not json over") == "500"
+    assert s2s.handle_request(json.dumps({"model_name": "Net"}) + "over") == "500"      # missing keys
+    assert s2s.handle_request(json.dumps(req) + "over\n") == "500"                       # :190 cuts four characters of the raw text
+    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(1)
+    cli = socket.create_connection(srv.getsockname())
+    conn, addr = srv.accept()
+    t = s2s.ServerThreading(conn, addr)
+    t.start()
+    payload = (json.dumps(req) + "over").encode()
+    cli.sendall(payload[:20])
+    cli.sendall(payload[20:])
+    assert cli.recv(1 << 16).decode() == "{}"
+    t.join(10)
+    cli.close()
+    srv.close()
+    res = {"image": [{"image_path": "a", "image_id": 0}], "annotations": [{"image_id": 0, "box": [1, 2, 3, 4], "predicted_class": "c", "conf": float(np.float32(0.93))}]}
+    assert s2s._reply_text(res) == "{'image': [{'image_path': 'a', 'image_id': 0}], 'annotations': [{'image_id': 0, 'box': [1, 2, 3, 4], 'predicted_class': 'c', 'conf': 0.93}]}"

@@ -252,3 +252,45 @@ def test_evaluate_one_img_from_files_equals_host_prepared_input(tmp_path):
         a = [ln.split()[0] for ln in open(tmp_path / "dev" / stem)]
         b = [ln.split()[0] for ln in open(tmp_path / "dev3" / stem)]
         assert len(a) == len(b)
+
+
+def test_socket_request_runs_the_hot_path(tmp_path, monkeypatch):
+    """tools/socket2springboot.py:33-123 + :174-213 end to end.  OpenCV is absent: a stand-in `cv2` module supplies `resize`
+    (any deterministic resize will do -- the check is that the reply equals the three hot-path statements run directly on the
+    same prepared input, not the filter)."""
+    import ast
+    import json
+    import sys
+    import types
+    from ccnet_amd import synth
+    from ccnet_amd.network.net import Net
+    from ccnet_amd.tools import demo, socket2springboot as s2s
+    from oracle import preprocess_oracle as po
+    fake = types.ModuleType("cv2")
+    fake.INTER_CUBIC = 2
+    fake.resize = lambda img, size, interpolation=None: po.resize_bicubic_u8(img, size[0], size[1])
+    monkeypatch.setitem(sys.modules, "cv2", fake)
+    net = Net(0.33, 0.5, 6, "silu")
+    path = str(tmp_path / "w.pth")
+    torch.save({"epoch": 1, "model": synth.synth_state_dict(net.state_dict(), seed=0, bn_calib="net"), "ap50": 0.0, "ap5095": 0.0}, path)
+    names = ["c%d" % i for i in range(6)]
+    rng = np.random.default_rng(11)
+    imgs = [rng.integers(0, 256, (200, 200, 3), dtype=np.uint8), rng.integers(0, 256, (120, 90, 3), dtype=np.uint8), np.zeros((5, 5), np.uint8)]
+    req = {"model_name": "Net", "model_path": path, "dataset": "NEUDET", "input_shape": [224, 224], "conf_thres": 0.3, "nms_thres": 0.6,
+           "image_path": ["a.jpg", "b.jpg", "grey.jpg"]}
+    reply = s2s.handle_request(json.dumps(req) + "over", class_names=names, images=imgs, device="cuda")
+    assert reply != "500"
+    got = ast.literal_eval(reply)
+    assert [d["image_id"] for d in got["image"]] == [0, 1, 2]          # the 1-channel file is listed but skipped (:66-73)
+    model = s2s._model_for(path, 6, "cuda")
+    want = []
+    for i in (0, 1):
+        data, info = demo.preprocess(imgs[i], [224, 224])
+        res = demo.predict(model, torch.from_numpy(data).to("cuda"), 6, [224, 224], info, 0.3, 0.6)
+        want.extend(demo.detections_to_annotations(res[0], i, names))
+    assert len(want) > 0 and len(got["annotations"]) == len(want)
+    for g, w in zip(got["annotations"], want):
+        assert g["image_id"] == w["image_id"] and g["box"] == w["box"] and g["predicted_class"] == w["predicted_class"]
+        assert g["conf"] == float(str(np.float32(w["conf"])))
+    # a second request reuses the loaded model
+    assert s2s._model_for(path, 6, "cuda") is model
