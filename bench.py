@@ -107,7 +107,7 @@ def main():
         dec = bbox.decode_outputs(outs, [S, S])
         dets = bbox.post_process(dec, 6, [S, S], info, args.conf, args.nms)
         if world > 1:
-            dets = all_gather_detections(dets, device=dev)
+            dets = all_gather_detections(dets, device=dev, max_local=B)
         return dets
 
     for _ in range(args.warmup):

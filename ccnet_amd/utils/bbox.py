@@ -19,6 +19,21 @@ def _require_cuda(t, what):
         raise RuntimeError("ccnet_amd.%s needs CUDA (ROCm) tensors; this build has no CPU path" % what)
 
 
+_hw_cache = {}
+
+
+def _image_hw(hw, device):
+    """int32 (B, 2) device tensor of (image_h, image_w); batches of a dataset mostly repeat the same sizes, so the small
+    host->device copy is made once per distinct tuple (bounded cache)."""
+    key = (hw, str(device))
+    t = _hw_cache.get(key)
+    if t is None:
+        if len(_hw_cache) >= 64:
+            _hw_cache.clear()
+        t = _hw_cache[key] = torch.tensor(hw, dtype=torch.int32).reshape(-1, 2).to(device)
+    return t
+
+
 def decode_outputs(outputs, input_shape):
     """outputs: list of (B, 5+nc, h_k, w_k) fp32 CUDA tensors (any b/c strides); input_shape = [in_h, in_w].
     Returns (B, sum h_k*w_k, 5+nc): [cx, cy, w, h] normalised, obj and class probabilities."""
@@ -58,11 +73,13 @@ def _nms(cand, counts, nmax, nms_thres, image_hw):
     ws = torch.empty(ops.nms_workspace_bytes(B, nmax) + 256, dtype=torch.uint8, device=dev)
     off = (-ws.data_ptr()) % 256
     ws = ws[off:]
-    det = torch.empty(B, nmax, 7, dtype=torch.float32, device=dev)
+    # rows and their counts share one buffer so that the caller fetches both with a single device->host copy
+    both = torch.empty(B * nmax * 7 + B, dtype=torch.float32, device=dev)
+    det = both[:B * nmax * 7].view(B, nmax, 7)
+    nkeep = both[B * nmax * 7:].view(torch.int32)
     keep_idx = torch.empty(B, nmax, dtype=torch.int32, device=dev)
-    nkeep = torch.empty(B, dtype=torch.int32, device=dev)
     ops.nms(cand, counts, nmax, nms_thres, image_hw, det, keep_idx, nkeep, ws)
-    return det, keep_idx, nkeep
+    return det, keep_idx, nkeep, both
 
 
 def nms_keep_indices(cand, counts, nms_thres):
@@ -72,7 +89,7 @@ def nms_keep_indices(cand, counts, nms_thres):
     cand = cand.float().contiguous()
     nmax = max(int(counts.cpu().max()), 1) if counts.numel() else 1
     hw = torch.ones(B, 2, dtype=torch.int32, device=cand.device)
-    det, keep_idx, nkeep = _nms(cand, counts.to(torch.int32).contiguous(), nmax, nms_thres, hw)
+    det, keep_idx, nkeep, _ = _nms(cand, counts.to(torch.int32).contiguous(), nmax, nms_thres, hw)
     nk = nkeep.cpu().numpy()
     ki = keep_idx.cpu().numpy()
     return [ki[b, :nk[b]].astype(np.int64) for b in range(B)]
@@ -87,8 +104,10 @@ def post_process(prediction, num_classes, input_shape, image_info, conf_thres=0.
     if A == 0 or B == 0:
         return [None for _ in range(B)]
     pred = prediction.float().contiguous()
-    hw = torch.tensor([[int(image_info[i][2]), int(image_info[i][1])] for i in range(B)], dtype=torch.int32).to(pred.device)
-    cand, counts, det, keep_idx, nkeep = _filter_and_nms(pred, num_classes, conf_thres, nms_thres, hw)
-    nk = nkeep.cpu().numpy()
-    det_h = det.cpu().numpy()
+    hw = _image_hw(tuple((int(image_info[i][2]), int(image_info[i][1])) for i in range(B)), pred.device)
+    cand, counts, det, keep_idx, nkeep, both = _filter_and_nms(pred, num_classes, conf_thres, nms_thres, hw)
+    host = both.cpu().numpy()
+    nmax = det.shape[1]
+    det_h = host[:B * nmax * 7].reshape(B, nmax, 7)
+    nk = host[B * nmax * 7:].view(np.int32)
     return [det_h[b, :nk[b]].copy() for b in range(B)]

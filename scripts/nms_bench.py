@@ -15,7 +15,7 @@ for n in (1000, 10000, 40000):
     bbox._nms(ct, counts, n, 0.6, hw); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):
-        det, keep, nk = bbox._nms(ct, counts, n, 0.6, hw)
+        det, keep, nk, _ = bbox._nms(ct, counts, n, 0.6, hw)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 5 * 1e3
     pairs = B * 6 * (n / 6) * (n / 6 - 1) / 2

@@ -246,6 +246,12 @@ def _gather_worker(rank, world, port, q):
     if rank == 1:
         local.append(None)
     out = all_gather_detections(local)
+    hinted = all_gather_detections(local, max_local=2)
+    assert len(hinted) == len(out) and all((a is None and b is None) or np.array_equal(a, b) for a, b in zip(out, hinted))
+    # one image with more rows than the first collective carries: every rank must take the second one
+    big = [np.full((300 + rank, 7), float(rank), np.float32)] if rank == 1 else [np.zeros((2, 7), np.float32)]
+    gb = all_gather_detections(big, max_local=1)
+    assert [g.shape[0] for g in gb] == [2, 301] and float(gb[1][300, 3]) == 1.0
     q.put((rank, [None if o is None else o.copy() for o in out]))
     dist.barrier()
     dist.destroy_process_group()
