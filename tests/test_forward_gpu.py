@@ -294,3 +294,73 @@ def test_socket_request_runs_the_hot_path(tmp_path, monkeypatch):
         assert g["conf"] == float(str(np.float32(w["conf"])))
     # a second request reuses the loaded model
     assert s2s._model_for(path, 6, "cuda") is model
+
+
+def test_headline_config_full_size_properties():
+    """BASELINE configs[1] as bench.py runs it (`net`, s, 6 classes, 640^2, 64 images, bf16, conf 0.5 / nms 0.6), checked
+    through size-independent properties: (1) decode of the device logits equals the oracle's decode of the same logits
+    (3e-6: exp/sigmoid ulps), (2) post_process of the device decode equals the oracle's post_process of that same tensor bit
+    for bit (rows, order, counts), (3) a second run reproduces every bit (HIP-graph replay included), (4) the Transformer
+    attends over the batch axis without positions or masks, so permuting the images permutes the logits (fp32, 2e-4: only
+    the summation order inside softmax / PV changes)."""
+    from ccnet_amd import synth
+    from ccnet_amd.utils import bbox
+    from oracle import ccnet_oracle as orc
+    B, S = 64, 640
+    x = torch.cat([synth.synth_images(8, S, S, seed=50 + i) for i in range(B // 8)], 0).to("cuda")
+    info = [[i, 500 + i, 400 - i] for i in range(B)]
+    net = _model("net", 0.33, 0.5, 6, "bf16")
+    runs = []
+    for _ in range(3):  # eager, capture, replay
+        outs = [o.clone() for o in net(x)]
+        dec = bbox.decode_outputs(outs, [S, S])
+        dets = bbox.post_process(dec, 6, [S, S], info, 0.5, 0.6)
+        runs.append((outs, dec, dets))
+    outs, dec, dets = runs[0]
+    assert dec.shape == (B, 8400, 11)
+    ref_dec = orc.decode_outputs([o.cpu() for o in outs], [S, S])
+    assert float((dec.cpu() - ref_dec).abs().max() / ref_dec.abs().max()) < 3e-6
+    ref_dets = orc.post_process(dec.cpu(), 6, [S, S], info, 0.5, 0.6)
+    total = 0
+    for b in range(B):
+        assert dets[b].shape == ref_dets[b].shape and np.array_equal(dets[b], ref_dets[b]), "image %d" % b
+        total += dets[b].shape[0]
+    assert total > B  # the synthetic net does detect things at this threshold
+    for o2, d2, t2 in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs, o2)) and torch.equal(dec, d2)
+        assert all(np.array_equal(a, b) for a, b in zip(dets, t2))
+    net32 = _model("net", 0.33, 0.5, 6, "fp32")
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).to("cuda")
+    a = [o.clone() for o in net32(x)]
+    b = net32(x[perm].contiguous())
+    torch.cuda.synchronize()
+    for lvl, (u, v) in enumerate(zip(a, b)):
+        err = float((u[perm] - v).abs().max() / u.abs().max())
+        assert err < 2e-4, "level %d: permutation changes logits by %.2e" % (lvl, err)
+
+
+def test_small_target_full_resolution_post_process_matches_oracle():
+    """BASELINE configs[4] geometry (`net_small_target`, 1280^2: four levels, 136 000 anchors per image) at batch 2, with the
+    confidence threshold placed so that about 10 000 candidates per image reach NMS: decode against the oracle's
+    decode of the same logits (3e-6) and filter + NMS + rescale against the oracle's post_process of the same decoded tensor,
+    bit for bit."""
+    from ccnet_amd import synth
+    from ccnet_amd.utils import bbox
+    from oracle import ccnet_oracle as orc
+    B, S = 2, 1280
+    net = _model("net_small_target", 0.33, 0.5, 6, "bf16")
+    x = synth.synth_images(B, S, S, seed=21).to("cuda")
+    outs = [o.clone() for o in net(x)]
+    assert [tuple(o.shape[2:]) for o in outs] == [(320, 320), (160, 160), (80, 80), (40, 40)]
+    dec = bbox.decode_outputs(outs, [S, S])
+    assert dec.shape == (B, 136000, 11)
+    ref_dec = orc.decode_outputs([o.cpu() for o in outs], [S, S])
+    assert float((dec.cpu() - ref_dec).abs().max() / ref_dec.abs().max()) < 3e-6
+    score = (dec[..., 4] * dec[..., 5:].max(-1).values).flatten()
+    conf = float(score.kthvalue(score.numel() - 20000).values)
+    info = [[0, 1920, 1080], [1, 1280, 1280]]
+    dets = bbox.post_process(dec, 6, [S, S], info, conf, 0.6)
+    ref = orc.post_process(dec.cpu(), 6, [S, S], info, conf, 0.6)
+    for b in range(B):
+        assert dets[b].shape == ref[b].shape and np.array_equal(dets[b], ref[b]), "image %d" % b
+    assert sum(d.shape[0] for d in dets) > 1000
