@@ -14,8 +14,8 @@ struct PlanOp {
     int lane;            // stream the op runs on (0 = the caller's)
     int wait_src;        // >= 0: this op is "lane `lane` waits for everything recorded so far on lane wait_src"
 };
-// One instantiated HIP graph of the whole plan per (device, image pointer): a forward is ~200 dependent launches of
-// 10-300 us kernels, and replaying them as a graph removes the per-launch host work and most of the dispatch gaps.
+// One instantiated HIP graph of the whole plan per (device, image pointer), when graphs are enabled (CCNET_GRAPH=1):
+// replaying removes the per-launch host work, but see graphs_enabled() for why eager side lanes are the default.
 struct PlanGraph {
     int device;
     const float* x;
@@ -132,10 +132,10 @@ namespace {
 bool lanes_enabled() {
     static int v = -1;
     if (v < 0) {
-        // opt-in: the persistent conv kernels fill every CU's LDS and registers, so side lanes find no room to run
-        // beside them (measured: 6.21 vs 6.28 ms per step eagerly, no difference under graph replay)
+        // side lanes run the recorded independent branches (head levels, the CBAM gates beside the fused Transformer) on
+        // their own streams: measured 5.85 vs 6.06 ms per bs64 step when launched eagerly.  CCNET_LANES=0 turns them off.
         const char* e = getenv("CCNET_LANES");
-        v = (e && atoi(e) != 0) ? 1 : 0;
+        v = (e && atoi(e) == 0) ? 0 : 1;
     }
     return v == 1;
 }
@@ -185,8 +185,10 @@ int run_eager(ccnet_plan* plan, const float* x_dev, hipStream_t st, bool lanes) 
 bool graphs_enabled() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("CCNET_NO_GRAPH");
-        v = (e && atoi(e) != 0) ? 0 : 1;
+        // opt-in (CCNET_GRAPH=1): on ROCm 7.2 a replayed graph runs its parallel branches one after the other and is no
+        // faster than eager launches on one stream (6.09 vs 6.06 ms), while eager launches on side lanes do overlap
+        const char* e = getenv("CCNET_GRAPH");
+        v = (e && atoi(e) != 0) ? 1 : 0;
     }
     return v == 1;
 }

@@ -492,6 +492,14 @@ class Compiler:
         l1 = self.csp("dark2.1", [self.down("dark2.0", l0)], bd, True, amff)
         l2 = self.csp("dark3.1", [self.down("dark3.0", l1)], n3, True, amff)
         l3 = self.csp("dark4.1", [self.down("dark4.0", l2)], bd * 3, True, amff)
+        side_gates = bool(c["vit"]) and not amff
+        if side_gates:
+            # the CBAM gates of dark3 / dark4 do not depend on dark5: on lane 3 they can fill the CUs that the fused
+            # Transformer (400 positions on 256 CUs) leaves idle in its second round
+            ops.plan_wait(3, 0)
+            ops.plan_set_lane(3)
+            g2, g3 = self.cbam("layer2_cbam", l2), self.cbam("layer3_cbam", l3)
+            ops.plan_set_lane(0)
         t = self.sppf("dark5.1", self.down("dark5.0", l3))
         tp["dark2"], tp["dark3"], tp["dark4"], tp["sppf"] = l1, l2, l3, t
         if c["vit"]:
@@ -503,6 +511,9 @@ class Compiler:
 
         if amff:
             g2, g3, g4 = self.eca("eca_3", l2), self.eca("eca_2", l3), self.eca("eca_1", l4)
+        elif side_gates:
+            g4 = self.cbam("layer4_cbam", l4)
+            ops.plan_wait(0, 3)
         else:
             g2, g3, g4 = self.cbam("layer2_cbam", l2), self.cbam("layer3_cbam", l3), self.cbam("layer4_cbam", l4)
 

@@ -300,7 +300,7 @@ def test_headline_config_full_size_properties():
     """BASELINE configs[1] as bench.py runs it (`net`, s, 6 classes, 640^2, 64 images, bf16, conf 0.5 / nms 0.6), checked
     through size-independent properties: (1) decode of the device logits equals the oracle's decode of the same logits
     (3e-6: exp/sigmoid ulps), (2) post_process of the device decode equals the oracle's post_process of that same tensor bit
-    for bit (rows, order, counts), (3) a second run reproduces every bit (HIP-graph replay included), (4) the Transformer
+    for bit (rows, order, counts), (3) further runs reproduce every bit (side-lane concurrency must not change results), (4) the Transformer
     attends over the batch axis without positions or masks, so permuting the images permutes the logits (fp32, 2e-4: only
     the summation order inside softmax / PV changes)."""
     from ccnet_amd import synth
@@ -311,7 +311,7 @@ def test_headline_config_full_size_properties():
     info = [[i, 500 + i, 400 - i] for i in range(B)]
     net = _model("net", 0.33, 0.5, 6, "bf16")
     runs = []
-    for _ in range(3):  # eager, capture, replay
+    for _ in range(3):
         outs = [o.clone() for o in net(x)]
         dec = bbox.decode_outputs(outs, [S, S])
         dets = bbox.post_process(dec, 6, [S, S], info, 0.5, 0.6)
