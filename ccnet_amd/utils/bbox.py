@@ -50,7 +50,8 @@ def decode_outputs(outputs, input_shape):
     A = sum(int(h.shape[2]) * int(h.shape[3]) for h in heads)
     out = torch.empty(B, A, nch, dtype=torch.float32, device=heads[0].device)
     if B * A:
-        ops.decode(heads, nch - 5, input_shape[0], input_shape[1], out)
+        with torch.cuda.device(out.device):  # launches go to the tensors' device, whatever the caller's current device is
+            ops.decode(heads, nch - 5, input_shape[0], input_shape[1], out)
     return out
 
 
@@ -89,7 +90,8 @@ def nms_keep_indices(cand, counts, nms_thres):
     cand = cand.float().contiguous()
     nmax = max(int(counts.cpu().max()), 1) if counts.numel() else 1
     hw = torch.ones(B, 2, dtype=torch.int32, device=cand.device)
-    det, keep_idx, nkeep, _ = _nms(cand, counts.to(torch.int32).contiguous(), nmax, nms_thres, hw)
+    with torch.cuda.device(cand.device):
+        det, keep_idx, nkeep, _ = _nms(cand, counts.to(torch.int32).contiguous(), nmax, nms_thres, hw)
     nk = nkeep.cpu().numpy()
     ki = keep_idx.cpu().numpy()
     return [ki[b, :nk[b]].astype(np.int64) for b in range(B)]
@@ -105,7 +107,8 @@ def post_process(prediction, num_classes, input_shape, image_info, conf_thres=0.
         return [None for _ in range(B)]
     pred = prediction.float().contiguous()
     hw = _image_hw(tuple((int(image_info[i][2]), int(image_info[i][1])) for i in range(B)), pred.device)
-    cand, counts, det, keep_idx, nkeep, both = _filter_and_nms(pred, num_classes, conf_thres, nms_thres, hw)
+    with torch.cuda.device(pred.device):
+        cand, counts, det, keep_idx, nkeep, both = _filter_and_nms(pred, num_classes, conf_thres, nms_thres, hw)
     host = both.cpu().numpy()
     nmax = det.shape[1]
     det_h = host[:B * nmax * 7].reshape(B, nmax, 7)

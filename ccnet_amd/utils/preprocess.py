@@ -81,6 +81,8 @@ def preprocess_group(src, out, input_shape, letterbox=False):
         raise TypeError("preprocess_group: uint8 CUDA source and float32 CUDA destination expected")
     if src.dim() not in (3, 4) or (src.dim() == 4 and src.shape[3] != 3):
         raise ValueError("preprocess_group: source must be (n, ih, iw, 3) or (n, ih, iw), got %s" % (tuple(src.shape),))
+    if src.device != out.device:
+        raise ValueError("preprocess_group: source on %s, destination on %s" % (src.device, out.device))
     src = src.contiguous()
     n, ih, iw = src.shape[:3]
     ch = 3 if src.dim() == 4 else 1
@@ -93,9 +95,10 @@ def preprocess_group(src, out, input_shape, letterbox=False):
     lut = _lut(src.device)
     ws_bytes = L.ccnet_preprocess_workspace_bytes(n, ih, nw)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=src.device)
-    _lib.check(L.ccnet_preprocess(src.data_ptr(), n, ih, iw, ch, ih * iw * ch, iw * ch, ch, out.data_ptr(), h, w, 3 * h * w, h * w, dx, dy, nw, nh,
-                                  hb.data_ptr(), hk.data_ptr(), hks, vb.data_ptr(), vk.data_ptr(), vks, lut.data_ptr(), 128, ws.data_ptr(), ws_bytes,
-                                  _lib.stream_ptr()))
+    with torch.cuda.device(src.device):
+        _lib.check(L.ccnet_preprocess(src.data_ptr(), n, ih, iw, ch, ih * iw * ch, iw * ch, ch, out.data_ptr(), h, w, 3 * h * w, h * w, dx, dy, nw, nh,
+                                      hb.data_ptr(), hk.data_ptr(), hks, vb.data_ptr(), vk.data_ptr(), vks, lut.data_ptr(), 128, ws.data_ptr(),
+                                      ws_bytes, _lib.stream_ptr()))
     return out
 
 
