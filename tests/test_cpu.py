@@ -433,3 +433,25 @@ def test_socket_protocol_over_a_real_connection():
     srv.close()
     res = {"image": [{"image_path": "a", "image_id": 0}], "annotations": [{"image_id": 0, "box": [1, 2, 3, 4], "predicted_class": "c", "conf": float(np.float32(0.93))}]}
     assert s2s._reply_text(res) == "{'image': [{'image_path': 'a', 'image_id': 0}], 'annotations': [{'image_id': 0, 'box': [1, 2, 3, 4], 'predicted_class': 'c', 'conf': 0.93}]}"
+
+
+def test_product_path_fails_loudly_without_the_hip_library(tmp_path):
+    """No CPU fallback: with the shared library absent every entry point raises instead of computing something else.  Run in a
+    child process because the loaded library is cached per process."""
+    import subprocess
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from ccnet_amd import _lib\n"
+        "from ccnet_amd.utils import preprocess as pp\n"
+        "for fn in (lambda: _lib.lib(), lambda: pp.resample_tables(10, 20), lambda: _lib.conv_pack_dims(1, 64, 576)):\n"
+        "    try:\n"
+        "        fn()\n"
+        "    except RuntimeError as e:\n"
+        "        assert 'is missing' in str(e) and 'no CPU fallback' in str(e), str(e)\n"
+        "    else:\n"
+        "        raise SystemExit('no error raised')\n"
+        "print('loud')\n" % ROOT)
+    env = dict(os.environ, CCNET_HIP_LIB=str(tmp_path / "nowhere" / "libccnet_hip.so"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "loud" in r.stdout, r.stdout + r.stderr
