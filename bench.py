@@ -83,11 +83,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    # CCNET_BENCH_REHEARSE=1: every rank on cuda:0 with gloo collectives -- a one-GPU rehearsal of the multi-rank control flow
+    # (barriers, max-over-ranks timing, detections all_gather); its numbers mean nothing
+    rehearse = world > 1 and os.environ.get("CCNET_BENCH_REHEARSE", "0") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 and not rehearse else 0)
+    cdev = torch.device("cpu") if rehearse else dev  # where collective payloads live
     torch.cuda.set_device(dev)
 
     from ccnet_amd import synth
@@ -107,7 +114,7 @@ def main():
         dec = bbox.decode_outputs(outs, [S, S])
         dets = bbox.post_process(dec, 6, [S, S], info, args.conf, args.nms)
         if world > 1:
-            dets = all_gather_detections(dets, device=dev, max_local=B)
+            dets = all_gather_detections(dets, device=cdev, max_local=B)
         return dets
 
     for _ in range(args.warmup):
@@ -123,7 +130,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
