@@ -113,11 +113,11 @@ NmsWs nms_ws(int B, int nmax) {
 }
 
 // offset boxes = boxes + cls * (max_coordinate + 1)  (torchvision batched_nms coordinate trick); scores = obj * cls_conf
-__global__ __launch_bounds__(256) void nms_prepare_kernel(const float* cand, const int* counts, int A, int np, float4* boxes, float* scores) {
+__global__ __launch_bounds__(256) void nms_prepare_kernel(const float* cand, const int* counts, int A, int np, int nmax, float4* boxes, float* scores) {
     __shared__ float red[4];
     __shared__ float maxc_s;
     const int b = blockIdx.x, t = threadIdx.x;
-    const int n = counts[b];
+    const int n = min(counts[b], nmax);  // an image with more candidates than the caller sized for is cut, never overrun
     const float* cb = cand + (size_t)b * A * 7;
     float m = -INFINITY;
     for (int i = t; i < n; i += 256) {
@@ -139,11 +139,11 @@ __global__ __launch_bounds__(256) void nms_prepare_kernel(const float* cand, con
 }
 
 // stable descending rank: rank(i) = #{j : s_j > s_i or (s_j == s_i and j < i)}
-__global__ __launch_bounds__(256) void nms_rank_kernel(const int* counts, int np, const float4* boxes, const float* scores, float4* sboxes,
+__global__ __launch_bounds__(256) void nms_rank_kernel(const int* counts, int np, int nmax, const float4* boxes, const float* scores, float4* sboxes,
                                                        int* order) {
     __shared__ float tile[256];
     const int b = blockIdx.y, t = threadIdx.x;
-    const int n = counts[b];
+    const int n = min(counts[b], nmax);
     if ((int)(blockIdx.x * 256) >= n) return;
     const int i = blockIdx.x * 256 + t;
     const float* sb = scores + (size_t)b * np;
@@ -166,10 +166,10 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const int* counts, int np
 }
 
 // one wave per 64x64 tile of the (sorted) pair matrix; lane = row, bit j = column
-__global__ __launch_bounds__(64) void nms_mask_kernel(const int* counts, int np, int W, const float4* sboxes, double thr, unsigned long long* mask) {
+__global__ __launch_bounds__(64) void nms_mask_kernel(const int* counts, int np, int W, int nmax, const float4* sboxes, double thr, unsigned long long* mask) {
     __shared__ float4 cols[64];
     const int b = blockIdx.z, rb = blockIdx.y, cbk = blockIdx.x;
-    const int n = counts[b];
+    const int n = min(counts[b], nmax);
     if (cbk < rb || rb * 64 >= n || cbk * 64 >= n) return;
     const int lane = threadIdx.x;
     const float4* sb = sboxes + (size_t)b * np;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const int* counts, int n
     __shared__ int kept_l[64];  // positions (0..63) of the boxes kept in the current chunk
     __shared__ int kept_n;
     const int b = blockIdx.x, t = threadIdx.x;
-    const int n = counts[b];
+    const int n = min(counts[b], nmax);
     const int nw = (n + 63) / 64;
     for (int w = t; w < nw; w += 256) removed[w] = 0ull;
     __syncthreads();
@@ -345,9 +345,9 @@ extern "C" int ccnet_nms(const float* cand_dev, const int32_t* counts_dev, int B
     const int W = ws.W;
     return ccnet_submit(
         [=](hipStream_t st, const float*) -> int {
-            hipLaunchKernelGGL(nms_prepare_kernel, dim3(B), dim3(256), 0, st, cand_dev, counts_dev, A, np, boxes, scores);
-            hipLaunchKernelGGL(nms_rank_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, st, counts_dev, np, boxes, scores, sboxes, order);
-            hipLaunchKernelGGL(nms_mask_kernel, dim3(W, W, B), dim3(64), 0, st, counts_dev, np, W, sboxes, nms_thres, mask);
+            hipLaunchKernelGGL(nms_prepare_kernel, dim3(B), dim3(256), 0, st, cand_dev, counts_dev, A, np, nmax, boxes, scores);
+            hipLaunchKernelGGL(nms_rank_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, st, counts_dev, np, nmax, boxes, scores, sboxes, order);
+            hipLaunchKernelGGL(nms_mask_kernel, dim3(W, W, B), dim3(64), 0, st, counts_dev, np, W, nmax, sboxes, nms_thres, mask);
             hipLaunchKernelGGL(nms_sweep_kernel, dim3(B), dim3(256), (size_t)W * 8, st, counts_dev, np, W, mask, order, nmax, keep_idx_dev, nkeep_dev);
             hipLaunchKernelGGL(nms_gather_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, st, cand_dev, A, nmax, keep_idx_dev, nkeep_dev,
                                image_hw_dev, det_dev);

@@ -55,29 +55,62 @@ def decode_outputs(outputs, input_shape):
     return out
 
 
+_nmax_guess = {}
+
+
 def _filter_and_nms(pred, num_classes, conf_thres, nms_thres, image_hw):
-    """pred (B, A, 5+nc) fp32 CUDA contiguous.  Returns (det (B,nmax,7), keep_idx (B,nmax), nkeep (B,), counts (B,)) on device,
-    after ONE host sync to size the NMS workspace."""
+    """pred (B, A, 5+nc) fp32 CUDA contiguous.  Returns (det_host (B,nmax,7), nkeep_host (B,)) as numpy arrays.
+
+    NMS needs the largest per-image candidate count to size its rows.  The first call for a (B, A, device) waits for the
+    counts; later calls launch NMS at once with an estimate from the previous call (1.25x, rounded up to 64) and fetch rows,
+    keep counts and candidate counts in ONE device->host copy.  If an image turned out to have more candidates than the
+    estimate (the kernels cut, never overrun), NMS is launched again with the exact maximum -- results do not depend on the
+    estimate, only the number of host round trips does."""
     B, A, _ = pred.shape
     dev = pred.device
+    key = (B, A, str(dev))
     cand = torch.empty(B, A, 7, dtype=torch.float32, device=dev)
-    counts = torch.empty(B, dtype=torch.int32, device=dev)
-    ops.filter_candidates(pred, num_classes, conf_thres, cand, counts)
-    nmax = int(counts.cpu().max())  # the one sync (a B-int copy; the maximum is taken on the host)
-    nmax = max(nmax, 1)
-    return (cand, counts) + _nms(cand, counts, nmax, nms_thres, image_hw)
+    nmax = _nmax_guess.get(key)
+    if nmax is None:
+        both = None
+        counts = torch.empty(B, dtype=torch.int32, device=dev)
+        ops.filter_candidates(pred, num_classes, conf_thres, cand, counts)
+        nmax = min(max(int(counts.cpu().max()), 1), A)  # waits for the filter kernel
+    else:
+        nmax = min(nmax, A)
+        both = _result_buffer(B, nmax, dev)
+        counts = both[B * nmax * 7 + B:].view(torch.int32)  # the filter kernel writes its counts straight into the result buffer
+        ops.filter_candidates(pred, num_classes, conf_thres, cand, counts)
+    while True:
+        if both is None:
+            both = _result_buffer(B, nmax, dev)
+            both[B * nmax * 7 + B:].view(torch.int32).copy_(counts)
+        _nms(cand, counts, nmax, nms_thres, image_hw, both)
+        host = both.cpu().numpy()
+        cmax = int(host[B * nmax * 7 + B:].view(np.int32).max())
+        if len(_nmax_guess) >= 64:
+            _nmax_guess.clear()
+        _nmax_guess[key] = min(A, max(64, -(-(cmax + cmax // 4) // 64) * 64))
+        if cmax <= nmax:
+            return host[:B * nmax * 7].reshape(B, nmax, 7), host[B * nmax * 7:B * nmax * 7 + B].view(np.int32)
+        nmax, both = min(cmax, A), None
 
 
-def _nms(cand, counts, nmax, nms_thres, image_hw):
+def _result_buffer(B, nmax, dev):
+    """rows (B, nmax, 7) | keep counts (B) | candidate counts (B): one buffer, so that a single copy brings all three."""
+    return torch.empty(B * nmax * 7 + 2 * B, dtype=torch.float32, device=dev)
+
+
+def _nms(cand, counts, nmax, nms_thres, image_hw, both=None):
     B = cand.shape[0]
     dev = cand.device
     ws = torch.empty(ops.nms_workspace_bytes(B, nmax) + 256, dtype=torch.uint8, device=dev)
     off = (-ws.data_ptr()) % 256
     ws = ws[off:]
-    # rows and their counts share one buffer so that the caller fetches both with a single device->host copy
-    both = torch.empty(B * nmax * 7 + B, dtype=torch.float32, device=dev)
+    if both is None:
+        both = _result_buffer(B, nmax, dev)
     det = both[:B * nmax * 7].view(B, nmax, 7)
-    nkeep = both[B * nmax * 7:].view(torch.int32)
+    nkeep = both[B * nmax * 7:B * nmax * 7 + B].view(torch.int32)
     keep_idx = torch.empty(B, nmax, dtype=torch.int32, device=dev)
     ops.nms(cand, counts, nmax, nms_thres, image_hw, det, keep_idx, nkeep, ws)
     return det, keep_idx, nkeep, both
@@ -108,9 +141,5 @@ def post_process(prediction, num_classes, input_shape, image_info, conf_thres=0.
     pred = prediction.float().contiguous()
     hw = _image_hw(tuple((int(image_info[i][2]), int(image_info[i][1])) for i in range(B)), pred.device)
     with torch.cuda.device(pred.device):
-        cand, counts, det, keep_idx, nkeep, both = _filter_and_nms(pred, num_classes, conf_thres, nms_thres, hw)
-    host = both.cpu().numpy()
-    nmax = det.shape[1]
-    det_h = host[:B * nmax * 7].reshape(B, nmax, 7)
-    nk = host[B * nmax * 7:].view(np.int32)
+        det_h, nk = _filter_and_nms(pred, num_classes, conf_thres, nms_thres, hw)
     return [det_h[b, :nk[b]].copy() for b in range(B)]

@@ -149,7 +149,9 @@ int ccnet_decode(const float* const* head_dev, const int64_t* sb, const int64_t*
 int ccnet_filter(const float* pred_dev, int B, int A, int nc, float conf_thres, float* cand_dev, int32_t* counts_dev,
                  ccnet_stream stream);
 /* post_process part 2 (utils/bbox.py:133-158): torchvision.ops.boxes.batched_nms (0.9.0 coordinate trick; third party,
- * see DESIGN.md) + gather + rescale to image pixels.  nmax >= max(counts).  image_hw_dev: int32 [B][2] = (ih, iw).
+ * see DESIGN.md) + gather + rescale to image pixels.  nmax = rows provided per image: results are exact when
+ * nmax >= max(counts); an image with more candidates is processed on its first nmax only (never overrun), so a caller
+ * may launch with an estimate and look at counts afterwards.  image_hw_dev: int32 [B][2] = (ih, iw).
  * det_dev: fp32 [B][nmax][7] rows [top,left,bottom,right,obj,cls_conf,cls_id] in descending score order;
  * keep_idx_dev: int32 [B][nmax] indices into the image's candidate list; nkeep_dev: int32 [B].
  * workspace_dev: ccnet_nms_workspace_bytes(B, nmax) bytes. */

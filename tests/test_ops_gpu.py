@@ -529,3 +529,44 @@ def test_nms_full_size_properties():
         sub = ct[b:b + 1, k].contiguous()
         again = bbox.nms_keep_indices(sub, torch.tensor([k.numel()], dtype=torch.int32, device=DEV), thr)[0]
         assert again.shape[0] == k.numel() and np.array_equal(again, np.arange(k.numel()))
+
+
+def test_post_process_estimate_too_small_is_repaired_and_abi_never_overruns():
+    """post_process launches NMS with a row estimate from the previous call and verifies it from the counts that come back with
+    the results: a too small estimate must cost one more launch, never a wrong answer.  And the C ABI itself: ccnet_nms with
+    nmax below an image's count works on the first nmax candidates only (no overrun of the nmax-sized buffers)."""
+    from oracle import ccnet_oracle as orc
+    from ccnet_amd import ops
+    from ccnet_amd.utils import bbox
+    g = torch.Generator().manual_seed(48)
+    B, A, nc = 4, 2000, 6
+    pred = torch.rand(B, A, 5 + nc, generator=g)
+    pred[..., 2:4] = pred[..., 2:4] * 0.15 + 0.01
+    pred[2, :, 4] *= 0.2
+    info = [[i, 320, 240] for i in range(B)]
+    ref = orc.post_process(pred, nc, [160, 256], info, 0.3, 0.5)
+    d = pred.to(DEV)
+    key = (B, A, str(d.device))
+    for guess in (None, 1, 64, 4096):   # first call (waits for counts), far too small, too small, larger than A
+        bbox._nmax_guess.pop(key, None)
+        if guess is not None:
+            bbox._nmax_guess[key] = guess
+        got = bbox.post_process(d, nc, [160, 256], info, 0.3, 0.5)
+        for a, b in zip(got, ref):
+            assert a.shape == b.shape and np.array_equal(a, b), guess
+        assert 64 <= bbox._nmax_guess[key] <= A
+    # direct ABI call with nmax smaller than the counts
+    cand = torch.empty(B, A, 7, device=DEV)
+    counts = torch.empty(B, dtype=torch.int32, device=DEV)
+    ops.filter_candidates(d, nc, 0.3, cand, counts)
+    assert int(counts.max()) > 100
+    nmax = 100
+    hw = torch.ones(B, 2, dtype=torch.int32, device=DEV)
+    det, keep_idx, nkeep, _ = bbox._nms(cand, counts, nmax, 0.5, hw)
+    torch.cuda.synchronize()
+    nk = nkeep.cpu().numpy()
+    assert (nk <= nmax).all() and (nk > 0).any()
+    small = bbox.nms_keep_indices(cand[:, :nmax].contiguous(), torch.clamp(counts, max=nmax), 0.5)
+    ki = keep_idx.cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(ki[b, :nk[b]], small[b])
