@@ -8,10 +8,12 @@ import collections, csv, json, re, sys
 
 prof, log, out = sys.argv[1:4]
 ops = []
+op_ms = []
 for line in open(log):
     m = re.match(r"\s+op\s+(\d+)\s+conv\s+([\d.]+) ms\s+[\d.]+ TF/s\s+[\d.]+ GB/s\s+([\d.]+) GF\s+([\d.]+) MB", line)
     if m:
         ops.append((float(m.group(3)) * 1e9, float(m.group(4)) * 1e6))
+        op_ms.append(float(m.group(2)))
 n = len(ops)
 
 def per_dispatch(path):
@@ -36,5 +38,20 @@ for name, g in res.items():
     o[name] = {"launches": int(g["n"]), "algorithmic_bytes_per_launch": g["alg_bytes"] / g["n"],
                "hbm_bytes_per_launch": (g["fetch_x2"] + g["write"]) / g["n"],
                "read_bytes_per_launch": g["fetch_x2"] / g["n"], "write_bytes_per_launch": g["write"] / g["n"]}
+# the same grouping applied to the one-stream kernel trace (rocprofv3 --kernel-trace, CCNET_LANES=0), when present: the average
+# launch duration bench.py's live HIP-event timing of this group has to agree with
+import os
+tr = prof + "/trace_serial/t_kernel_trace.csv"
+if os.path.exists(tr):
+    rows = [r for r in csv.DictReader(open(tr)) if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv_patch", "conv_generic"))]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+    if len(dur) % n == 0:
+        rr = len(dur) // n
+        for name in ("hot", "thin"):
+            ks = [k for k, (fl, by) in enumerate(ops) if (fl / by >= ridge) == (name == "hot")]
+            o[name]["trace_avg_launch_us"] = sum(sum(dur[k::n]) / rr for k in ks) / len(ks)
+            o[name]["bench_event_avg_launch_us"] = sum(ms for k, ms in enumerate(op_ms) if k in set(ks)) * 1e3 / len(ks)
+        o["trace_forwards_averaged"] = rr
 json.dump(o, open(out, "w"), indent=1)
 print(json.dumps(o, indent=1))
