@@ -16,6 +16,10 @@ SHAPES = {  # name: (B, H, W, cin, cout, k, stride, pad)
     "lin_256_1024": (1, 1, 25600, 256, 1024, 1, 1, 0),
     "lin_1024_256": (1, 1, 25600, 1024, 256, 1, 1, 0),
     "c3_512_20": (64, 20, 20, 512, 512, 3, 1, 1),
+    "c3_1024_512_20": (64, 20, 20, 1024, 512, 3, 1, 1),
+    "c3_128_20": (64, 20, 20, 128, 128, 3, 1, 1),
+    "c1_512_20": (64, 20, 20, 512, 512, 1, 1, 0),
+    "c1_1024_512_20": (64, 20, 20, 1024, 512, 1, 1, 0),
 }
 names = sys.argv[1:] or list(SHAPES)
 for name in names:
