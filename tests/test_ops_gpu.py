@@ -570,3 +570,17 @@ def test_post_process_estimate_too_small_is_repaired_and_abi_never_overruns():
     ki = keep_idx.cpu().numpy()
     for b in range(B):
         assert np.array_equal(ki[b, :nk[b]], small[b])
+
+
+def test_conv2d_random_sweep():
+    """scripts/conv_fuzz.py: 120 seeded random conv problems (kernel sizes 1/3/5/6/7, strides, one and two segments with an
+    upsampled first one, residuals, every activation, both dtypes, odd batch sizes) against torch -- so that each dispatch
+    branch of ccnet_conv2d (halo-patch, LDS-DMA implicit GEMM, flat 1x1, generic fallback) sees shapes its listed cases do not."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "conv_fuzz.py")
+    spec = importlib.util.spec_from_file_location("conv_fuzz", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, worst = mod.run(120, 7, verbose=False)
+    assert bad == 0 and len(worst) >= 8, worst
