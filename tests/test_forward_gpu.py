@@ -364,3 +364,15 @@ def test_small_target_full_resolution_post_process_matches_oracle():
     for b in range(B):
         assert dets[b].shape == ref[b].shape and np.array_equal(dets[b], ref[b]), "image %d" % b
     assert sum(d.shape[0] for d in dets) > 1000
+
+
+def test_odd_batches_and_non_square_inputs_all_nets():
+    """scripts/net_sweep.py, one case per net: odd batch sizes and non-square inputs (the fixtures are 224^2 / 160x256, batch
+    1-2).  fp32 logits vs the oracle <= 1e-3, bf16 vs fp32 rms < 8 %, decode 3e-6, post_process bit-exact on the device logits."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "net_sweep.py")
+    spec = importlib.util.spec_from_file_location("net_sweep", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cases = [("net", 3, 96, 160), ("net_old", 2, 128, 96), ("net_deploy", 7, 64, 96), ("net_amff", 3, 64, 160), ("net_small_target", 3, 96, 64)]
+    assert mod.run(cases, verbose=False) < 1e-3
