@@ -4,8 +4,27 @@
 
 namespace {
 
-template <typename T> struct Vec16;  // 16 bytes of channels, max in the element domain
+// 16 bytes of channels.  The SPPF cascade compares in an ORDER-PRESERVING INTEGER domain: a finite float's bit pattern becomes
+// a monotonic signed integer by flipping its magnitude bits when the sign is set (x ^ ((x >> sign) & magnitude mask), an
+// involution), so a max over bf16 pairs is one v_pk_max_i16 per dword instead of unpack / fmaxf / repack (~30 VALU per
+// 16 bytes, which made the kernel VALU-bound: a wave64 VALU instruction takes four cycles on a SIMD).  Planes live in LDS
+// in that domain; values are mapped on the way in and on the way out.  (-0.0 orders below +0.0; NaNs are not expected.)
+typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+template <typename T> struct Vec16;
 template <> struct Vec16<__bf16> {
+    static __device__ __forceinline__ unsigned key1(unsigned x) {
+        const s16x2_t sx = __builtin_bit_cast(s16x2_t, x);
+        const s16x2_t sg = sx >> (short)15;  // 0 or -1 per half
+        return x ^ (__builtin_bit_cast(unsigned, sg) & 0x7FFF7FFFu);
+    }
+    static __device__ __forceinline__ unsigned max1(unsigned a, unsigned b) {
+        const s16x2_t x = __builtin_bit_cast(s16x2_t, a), y = __builtin_bit_cast(s16x2_t, b);
+        return __builtin_bit_cast(unsigned, __builtin_elementwise_max(x, y));
+    }
+    static __device__ __forceinline__ uint4 key(const uint4& a) { return make_uint4(key1(a.x), key1(a.y), key1(a.z), key1(a.w)); }
+    static __device__ __forceinline__ uint4 kmax(const uint4& a, const uint4& b) {
+        return make_uint4(max1(a.x, b.x), max1(a.y, b.y), max1(a.z, b.z), max1(a.w, b.w));
+    }
     static __device__ __forceinline__ uint4 vmax(const uint4& a, const uint4& b) {
         float fa[8], fb[8];
         unpack8(a, fa); unpack8(b, fb);
@@ -15,50 +34,61 @@ template <> struct Vec16<__bf16> {
     }
 };
 template <> struct Vec16<float> {
+    static __device__ __forceinline__ unsigned key1(unsigned x) { return x ^ ((unsigned)((int)x >> 31) & 0x7FFFFFFFu); }
+    static __device__ __forceinline__ unsigned max1(unsigned a, unsigned b) { return (unsigned)max((int)a, (int)b); }
+    static __device__ __forceinline__ uint4 key(const uint4& a) { return make_uint4(key1(a.x), key1(a.y), key1(a.z), key1(a.w)); }
+    static __device__ __forceinline__ uint4 kmax(const uint4& a, const uint4& b) {
+        return make_uint4(max1(a.x, b.x), max1(a.y, b.y), max1(a.z, b.z), max1(a.w, b.w));
+    }
     static __device__ __forceinline__ uint4 vmax(const uint4& a, const uint4& b) {
         float4 x = __builtin_bit_cast(float4, a), y = __builtin_bit_cast(float4, b);
         return __builtin_bit_cast(uint4, make_float4(fmaxf(x.x, y.x), fmaxf(x.y, y.y), fmaxf(x.z, y.z), fmaxf(x.w, y.w)));
     }
 };
 
-// One block = one image x one 16-byte channel group; the whole H x W plane of that group lives in LDS.
+// One block = one image x `gpb` adjacent 16-byte channel groups; the H x W planes of those groups live in LDS.  Adjacent
+// lanes take adjacent groups of one pixel, so a wave's loads and stores cover gpb*16 contiguous bytes per pixel (one group
+// per block touched 16 bytes out of every 2 KB pixel row: a quarter of each 64-byte memory access was used).
 // torch max_pool2d pads with -inf, i.e. out-of-image taps are skipped.  NaN handling differs from torch
 // (fmaxf drops NaN, torch propagates); inputs here are finite activations.
 template <typename T>
-__global__ __launch_bounds__(256) void sppf_kernel(unsigned char* buf, int ldc, int coff, int C, int H, int W) {
+__global__ __launch_bounds__(256) void sppf_kernel(unsigned char* buf, int ldc, int coff, int C, int H, int W, int lg, int G) {
     extern __shared__ __align__(16) unsigned char dyn[];
-    uint4* cur = (uint4*)dyn;
-    uint4* tmp = cur + H * W;
     constexpr int EPC = 16 / (int)sizeof(T);
-    const int g = blockIdx.x, b = blockIdx.y;
-    const int HW = H * W;
-    unsigned char* base = buf + ((size_t)b * HW * ldc + coff + g * EPC) * sizeof(T);
+    const int ng = 1 << lg;  // groups per block, a power of two that divides G
+    const int g0 = blockIdx.x * ng, b = blockIdx.y;
+    const int HW = H * W, items = HW << lg;
+    uint4* cur = (uint4*)dyn;          // [HW][ng]: adjacent lanes read adjacent 16-byte slots
+    uint4* tmp = cur + items;
+    unsigned char* base = buf + ((size_t)b * HW * ldc + coff + g0 * EPC) * sizeof(T);
     const size_t pstride = (size_t)ldc * sizeof(T);
-    for (int i = threadIdx.x; i < HW; i += 256) cur[i] = *(const uint4*)(base + i * pstride);
+    const float rw = 1.0f / (float)W;
+    for (int i = threadIdx.x; i < items; i += 256) {
+        const int pix = i >> lg, sub = i & (ng - 1);
+        cur[i] = Vec16<T>::key(*(const uint4*)(base + pix * pstride + sub * 16));
+    }
     __syncthreads();
     for (int level = 1; level <= 3; ++level) {
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            int y = i / W, x = i - y * W;
+        for (int i = threadIdx.x; i < items; i += 256) {
+            const int pix = i >> lg;
+            const int y = (int)(((float)pix + 0.5f) * rw), x = pix - y * W;  // exact for H*W <= 5120
             uint4 m = cur[i];
 #pragma unroll
-            for (int d = -2; d <= 2; ++d) {
-                int xx = x + d;
-                if (d != 0 && (unsigned)xx < (unsigned)W) m = Vec16<T>::vmax(m, cur[y * W + xx]);
-            }
+            for (int d = -2; d <= 2; ++d)
+                if (d != 0 && (unsigned)(x + d) < (unsigned)W) m = Vec16<T>::kmax(m, cur[i + d * ng]);
             tmp[i] = m;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            int y = i / W, x = i - y * W;
+        for (int i = threadIdx.x; i < items; i += 256) {
+            const int pix = i >> lg, sub = i & (ng - 1);
+            const int y = (int)(((float)pix + 0.5f) * rw);
             uint4 m = tmp[i];
 #pragma unroll
-            for (int d = -2; d <= 2; ++d) {
-                int yy = y + d;
-                if (d != 0 && (unsigned)yy < (unsigned)H) m = Vec16<T>::vmax(m, tmp[yy * W + x]);
-            }
+            for (int d = -2; d <= 2; ++d)
+                if (d != 0 && (unsigned)(y + d) < (unsigned)H) m = Vec16<T>::kmax(m, tmp[i + d * W * ng]);
             // cur[i] is only read by this thread in this pass (the pass reads tmp), so update in place
             cur[i] = m;
-            *(uint4*)(base + i * pstride + (size_t)level * C * sizeof(T)) = m;
+            *(uint4*)(base + pix * pstride + sub * 16 + (size_t)level * C * sizeof(T)) = Vec16<T>::key(m);
         }
         __syncthreads();
     }
@@ -98,17 +128,23 @@ extern "C" int ccnet_sppf_pool(ccnet_slice buf, int dtype, int B, int H, int W, 
     CC_REQUIRE(cc_dtype_ok(dtype) && cc_slice_vec_ok(buf, dtype) && buf.shift == 0, "sppf_pool: bad slice");
     CC_REQUIRE(buf.ldc >= buf.coff + 4 * buf.C, "sppf_pool: buffer must hold 4*C channels from coff (ldc=%d coff=%d C=%d)", buf.ldc, buf.coff, buf.C);
     CC_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0, "sppf_pool: bad geometry");
-    size_t lds = (size_t)H * W * 16 * 2;
-    CC_REQUIRE(lds <= 160 * 1024, "sppf_pool: %dx%d plane does not fit in LDS (max H*W = 5120)", H, W);
-    int G = buf.C / (16 / cc_esize(dtype));
+    CC_REQUIRE((size_t)H * W * 32 <= 160 * 1024, "sppf_pool: %dx%d plane does not fit in LDS (max H*W = 5120)", H, W);
+    const int G = buf.C / (16 / cc_esize(dtype));
+    // channel groups per block: a power of two that divides G, as many as keep a block within ~52 KB of LDS (three blocks per
+    // CU), at most 8 (128 contiguous bytes per pixel)
+    int lg = 0;
+    while (lg < 3 && (G % (2 << lg)) == 0 && (size_t)H * W * 32 * (2 << lg) <= 52 * 1024) ++lg;
+    const int gpb = 1 << lg;
+    const size_t lds = (size_t)H * W * 32 * gpb;
+    const int gx = (G + gpb - 1) / gpb;
     return ccnet_submit(
         [=](hipStream_t st, const float*) -> int {
             if (dtype == CCNET_BF16) {
                 if (lds > 64 * 1024) CC_HIP(hipFuncSetAttribute((const void*)sppf_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(sppf_kernel<__bf16>, dim3(G, B), dim3(256), lds, st, (unsigned char*)buf.ptr, buf.ldc, buf.coff, buf.C, H, W);
+                hipLaunchKernelGGL(sppf_kernel<__bf16>, dim3(gx, B), dim3(256), lds, st, (unsigned char*)buf.ptr, buf.ldc, buf.coff, buf.C, H, W, lg, G);
             } else {
                 if (lds > 64 * 1024) CC_HIP(hipFuncSetAttribute((const void*)sppf_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(sppf_kernel<float>, dim3(G, B), dim3(256), lds, st, (unsigned char*)buf.ptr, buf.ldc, buf.coff, buf.C, H, W);
+                hipLaunchKernelGGL(sppf_kernel<float>, dim3(gx, B), dim3(256), lds, st, (unsigned char*)buf.ptr, buf.ldc, buf.coff, buf.C, H, W, lg, G);
             }
             CC_LAUNCH_CHECK();
             return CCNET_OK;
