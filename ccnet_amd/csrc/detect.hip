@@ -112,6 +112,32 @@ NmsWs nms_ws(int B, int nmax) {
     return w;
 }
 
+// torchvision nms: areas and the intersection in fp32, ovr = inter / (area_i + area_j - inter) compared as a double against
+// the threshold; a NaN overlap (0/0 of two empty boxes) compares false and never suppresses.  Shared by both NMS paths.
+__device__ __forceinline__ bool suppresses(const float4& bi, float ai, const float4& bj, double thr) {
+    const float aj = (bj.z - bj.x) * (bj.w - bj.y);
+    const float w = fmaxf(0.0f, fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x));
+    const float h = fmaxf(0.0f, fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y));
+    const float inter = w * h;
+    const float ovr = inter / ((ai + aj) - inter);
+    return (double)ovr > thr;
+}
+
+// det row = candidate row rescaled like the numpy tail of post_process (bbox.py:145-158): fp32 centre / size arithmetic, then a
+// float64 multiply by the image size.  Shared by both NMS paths.
+__device__ __forceinline__ void write_det(const float* r, const int* image_hw, int b, float* d) {
+    const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+    const float cx = (x1 + x2) / 2, cy = (y1 + y2) / 2;
+    const float w = x2 - x1, h = y2 - y1;
+    const float top = cy - (h / 2.f), left = cx - (w / 2.f), bottom = cy + (h / 2.f), right = cx + (w / 2.f);
+    const double ih = (double)image_hw[b * 2], iw = (double)image_hw[b * 2 + 1];
+    d[0] = (float)((double)top * ih);
+    d[1] = (float)((double)left * iw);
+    d[2] = (float)((double)bottom * ih);
+    d[3] = (float)((double)right * iw);
+    d[4] = r[4]; d[5] = r[5]; d[6] = r[6];
+}
+
 // offset boxes = boxes + cls * (max_coordinate + 1)  (torchvision batched_nms coordinate trick); scores = obj * cls_conf
 __global__ __launch_bounds__(256) void nms_prepare_kernel(const float* cand, const int* counts, int A, int np, int nmax, float4* boxes, float* scores) {
     __shared__ float red[4];
@@ -185,13 +211,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const int* counts, int np,
     for (int j = 0; j < jn; ++j) {
         const int gj = cbk * 64 + j;
         if (gj <= i) continue;
-        const float4 bj = cols[j];
-        const float aj = (bj.z - bj.x) * (bj.w - bj.y);
-        const float w = fmaxf(0.0f, fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x));
-        const float h = fmaxf(0.0f, fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y));
-        const float inter = w * h;
-        const float ovr = inter / ((ai + aj) - inter);
-        if ((double)ovr > thr) bits |= 1ull << j;  // NaN compares false: never suppresses
+        if (suppresses(bi, ai, cols[j], thr)) bits |= 1ull << j;
     }
     mask[((size_t)b * np + i) * W + cbk] = bits;
 }
@@ -266,18 +286,119 @@ __global__ __launch_bounds__(256) void nms_gather_kernel(const float* cand, int 
     const int b = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= nkeep[b]) return;
-    const float* r = cand + ((size_t)b * A + keep_idx[(size_t)b * nmax + k]) * 7;
-    const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
-    const float cx = (x1 + x2) / 2, cy = (y1 + y2) / 2;
-    const float w = x2 - x1, h = y2 - y1;
-    const float top = cy - (h / 2.f), left = cx - (w / 2.f), bottom = cy + (h / 2.f), right = cx + (w / 2.f);
-    const double ih = (double)image_hw[b * 2], iw = (double)image_hw[b * 2 + 1];
-    float* d = det + ((size_t)b * nmax + k) * 7;
-    d[0] = (float)((double)top * ih);
-    d[1] = (float)((double)left * iw);
-    d[2] = (float)((double)bottom * ih);
-    d[3] = (float)((double)right * iw);
-    d[4] = r[4]; d[5] = r[5]; d[6] = r[6];
+    write_det(cand + ((size_t)b * A + keep_idx[(size_t)b * nmax + k]) * 7, image_hw, b, det + ((size_t)b * nmax + k) * 7);
+}
+
+// ---- the whole NMS of one image in ONE block, for nmax <= SMALL_NMAX candidates per image: prepare, rank, mask, sweep and
+// gather as above, with the offset boxes, the sorted boxes, the order and the pair bitmask in LDS (52 KB) instead of the
+// workspace.  Five dependent launches of microsecond kernels become one; the arithmetic is the same device functions.
+constexpr int SMALL_NMAX = 512, SMALL_W = SMALL_NMAX / 64;
+
+__global__ __launch_bounds__(256) void nms_small_kernel(const float* cand, const int* counts, int A, int nmax, double thr, const int* image_hw, float* det,
+                                                        int* keep_idx, int* nkeep) {
+    __shared__ float4 boxes[SMALL_NMAX];
+    __shared__ float4 sboxes[SMALL_NMAX];
+    __shared__ float scores[SMALL_NMAX];
+    __shared__ int order[SMALL_NMAX];
+    __shared__ int kept_s[SMALL_NMAX];  // candidate indices of the kept boxes, score order
+    __shared__ unsigned long long mask[SMALL_NMAX * SMALL_W];
+    __shared__ float red[4];
+    __shared__ float maxc_s;
+    __shared__ int total_s;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int n = min(min(counts[b], nmax), SMALL_NMAX);
+    const int nw = (n + 63) / 64;
+    const float* cb = cand + (size_t)b * A * 7;
+    // prepare
+    float m = -INFINITY;
+    for (int i = t; i < n; i += 256) {
+        const float* r = cb + (size_t)i * 7;
+        m = fmaxf(m, fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])));
+    }
+    m = wave_max(m);
+    if ((t & 63) == 0) red[t >> 6] = m;
+    __syncthreads();
+    if (t == 0) maxc_s = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    const float step = maxc_s + 1.0f;
+    for (int i = t; i < n; i += 256) {
+        const float* r = cb + (size_t)i * 7;
+        const float off = r[6] * step;
+        boxes[i] = make_float4(r[0] + off, r[1] + off, r[2] + off, r[3] + off);
+        scores[i] = r[4] * r[5];
+    }
+    __syncthreads();
+    // stable descending rank
+    for (int i = t; i < n; i += 256) {
+        const float si = scores[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float sj = scores[j];
+            rank += (sj > si || (sj == si && j < i)) ? 1 : 0;
+        }
+        order[rank] = i;
+        sboxes[rank] = boxes[i];
+    }
+    __syncthreads();
+    // pair bitmask: item = (row i, word w), only words at or after the row's own
+    for (int it = t; it < n * nw; it += 256) {
+        const int i = it / nw, w = it - i * nw;
+        unsigned long long bits = 0ull;
+        if (w >= (i >> 6)) {
+            const float4 bi = sboxes[i];
+            const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+            const int j0 = w * 64, jn = min(64, n - j0);
+            for (int j = 0; j < jn; ++j)
+                if (j0 + j > i && suppresses(bi, ai, sboxes[j0 + j], thr)) bits |= 1ull << j;
+        }
+        mask[i * SMALL_W + w] = bits;
+    }
+    __syncthreads();
+    // greedy sweep by wave 0, 64 sorted boxes at a time
+    if (t < 64) {
+        unsigned long long removed[SMALL_W];
+#pragma unroll
+        for (int w = 0; w < SMALL_W; ++w) removed[w] = 0ull;
+        int total = 0;
+#pragma unroll
+        for (int c = 0; c < SMALL_W; ++c) {
+            if (c < nw) {
+                const int i = c * 64 + t;
+                const unsigned long long diag = i < n ? mask[i * SMALL_W + c] : 0ull;
+                unsigned long long rem = removed[c];
+                unsigned long long kept = 0ull;
+                const int jn = min(64, n - c * 64);
+                for (int j = 0; j < jn; ++j) {
+                    const unsigned long long dj = __shfl(diag, j, 64);
+                    if (!((rem >> j) & 1ull)) {
+                        kept |= 1ull << j;
+                        rem |= dj;
+                    }
+                }
+                const bool mine = (kept >> t) & 1ull;
+                if (mine) kept_s[total + __popcll(kept & ((1ull << t) - 1ull))] = order[i];
+                total += __popcll(kept);
+                // OR the rows of the kept boxes into the words ahead (every lane ends up with the same words)
+#pragma unroll
+                for (int w = c + 1; w < SMALL_W; ++w) {
+                    unsigned long long v = (mine && w < nw) ? mask[i * SMALL_W + w] : 0ull;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+                    removed[w] |= v;
+                }
+            }
+        }
+        if (t == 0) {
+            nkeep[b] = total;
+            total_s = total;
+        }
+    }
+    __syncthreads();
+    for (int k = t; k < total_s; k += 256) {
+        const int src = kept_s[k];
+        keep_idx[(size_t)b * nmax + k] = src;
+        write_det(cb + (size_t)src * 7, image_hw, b, det + ((size_t)b * nmax + k) * 7);
+    }
 }
 
 }  // namespace
@@ -343,6 +464,15 @@ extern "C" int ccnet_nms(const float* cand_dev, const int32_t* counts_dev, int B
     int* order = (int*)(base + ws.order);
     unsigned long long* mask = (unsigned long long*)(base + ws.mask);
     const int W = ws.W;
+    if (nmax <= SMALL_NMAX)
+        return ccnet_submit(
+            [=](hipStream_t st, const float*) -> int {
+                hipLaunchKernelGGL(nms_small_kernel, dim3(B), dim3(256), 0, st, cand_dev, counts_dev, A, nmax, nms_thres, image_hw_dev, det_dev,
+                                   keep_idx_dev, nkeep_dev);
+                CC_LAUNCH_CHECK();
+                return CCNET_OK;
+            },
+            stream, CCNET_OP_NMS, 0.0, 0.0);
     return ccnet_submit(
         [=](hipStream_t st, const float*) -> int {
             hipLaunchKernelGGL(nms_prepare_kernel, dim3(B), dim3(256), 0, st, cand_dev, counts_dev, A, np, nmax, boxes, scores);

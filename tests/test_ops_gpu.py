@@ -584,3 +584,37 @@ def test_conv2d_random_sweep():
     spec.loader.exec_module(mod)
     bad, worst = mod.run(120, 7, verbose=False)
     assert bad == 0 and len(worst) >= 8, worst
+
+
+def test_nms_single_block_path_equals_tiled_path():
+    """ccnet_nms runs the whole NMS of an image in one block when the caller provides <= 512 rows per image and the tiled
+    five-kernel pipeline otherwise; both use the same device arithmetic and must agree bit for bit (kept indices, order, rows),
+    and with the oracle.  Cases: dense overlaps, score ties, an empty image, exactly 512 and 64-multiples of candidates."""
+    from oracle import ccnet_oracle as orc
+    from ccnet_amd.utils import bbox
+    g = torch.Generator().manual_seed(5)
+    for n_per in ([0, 1, 63, 64, 65, 300, 512, 511], [128, 128, 17, 256]):
+        B, A = len(n_per), 600
+        cand = torch.zeros(B, A, 7)
+        for b, n in enumerate(n_per):
+            c = torch.rand(n, 2, generator=g) * 0.6 + 0.2
+            wh = torch.rand(n, 2, generator=g) * 0.25 + 0.02
+            cand[b, :n, 0:2] = c - wh / 2
+            cand[b, :n, 2:4] = c + wh / 2
+            cand[b, :n, 4] = (torch.rand(n, generator=g) * 8).floor() / 8 + 0.05   # many exact score ties
+            cand[b, :n, 5] = 1.0
+            cand[b, :n, 6] = torch.randint(0, 3, (n,), generator=g).float()
+        counts = torch.tensor(n_per, dtype=torch.int32)
+        hw = torch.tensor([[480, 640]] * B, dtype=torch.int32).to(DEV)
+        cd, ct = cand.to(DEV), counts.to(DEV)
+        res = {}
+        for nmax in (max(max(n_per), 1), 600):   # <= 512: single block; 600: tiled
+            det, keep_idx, nkeep, _ = bbox._nms(cd, ct, nmax, 0.5, hw)
+            torch.cuda.synchronize()
+            nk = nkeep.cpu().numpy()
+            res[nmax] = [(keep_idx[b, :nk[b]].cpu().numpy(), det[b, :nk[b]].cpu().numpy()) for b in range(B)]
+        small, tiled = res[max(max(n_per), 1)], res[600]
+        for b, n in enumerate(n_per):
+            assert np.array_equal(small[b][0], tiled[b][0]) and np.array_equal(small[b][1], tiled[b][1]), (n_per, b)
+            ref = orc.batched_nms_reference(cand[b, :n, :4].numpy(), (cand[b, :n, 4] * cand[b, :n, 5]).numpy(), cand[b, :n, 6].numpy(), 0.5)
+            assert np.array_equal(small[b][0], np.asarray(ref, dtype=small[b][0].dtype)), (n_per, b)
