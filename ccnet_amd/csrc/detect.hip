@@ -23,73 +23,104 @@ struct DecodeP {
     float* out;
 };
 
-// one thread per output ELEMENT (b, anchor, channel): with NHWC heads both the load and the store of a wave are contiguous
+// one thread per output ELEMENT (anchor, channel) of image blockIdx.y: with NHWC heads both the load and the store of a wave
+// are contiguous.  Index arithmetic is 32-bit (64-bit divisions made this kernel VALU-bound: 31 us for 47 MB).
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeP p) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)p.B * p.A * p.nch) return;
-    const long long idx = e / p.nch;
-    const int c = (int)(e - idx * p.nch);
-    const int a = (int)(idx % p.A), b = (int)(idx / p.A);
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    const unsigned per_img = (unsigned)p.A * (unsigned)p.nch;
+    if (e >= per_img) return;
+    const int b = blockIdx.y;
+    const int a = (int)(e / (unsigned)p.nch);
+    const int c = (int)(e - (unsigned)a * (unsigned)p.nch);
     int l = 0;
     while (l + 1 < p.nlev && a >= p.a0[l + 1]) ++l;
     const int r = a - p.a0[l];
     const int gy = r / p.w[l], gx = r - gy * p.w[l];
     const float raw = p.head[l][(long long)b * p.sb[l] + (long long)r * p.sp[l] + (long long)c * p.sc[l]];
     const float s = p.stride[l];
-    // ((raw + grid) * stride) / dim, exp(raw) * stride / dim: same op order as bbox.py:70-76
-    float v;
-    if (c == 0) v = ((raw + (float)gx) * s) / p.in_w;
-    else if (c == 1) v = ((raw + (float)gy) * s) / p.in_h;
-    else if (c == 2) v = (expf(raw) * s) / p.in_w;
-    else if (c == 3) v = (expf(raw) * s) / p.in_h;
-    else v = 1.0f / (1.0f + expf(-raw));
-    p.out[e] = v;
+    // ((raw + grid) * stride) / dim, (exp(raw) * stride) / dim, 1 / (1 + exp(-raw)): same operations on the same operands as
+    // bbox.py:39,70-76, arranged as ONE exponential and ONE division per element with selects around them -- a wave holds all
+    // channel kinds, and five divergent branches (each with its own IEEE division) made this kernel VALU-bound
+    const bool is_xy = c < 2, is_box = c < 4;
+    const float ex = expf(is_box ? raw : -raw);
+    const float g = (c == 0) ? (float)gx : (float)gy;
+    const float num = is_xy ? (raw + g) * s : (is_box ? ex * s : 1.0f);
+    const float den = is_box ? ((c & 1) ? p.in_h : p.in_w) : 1.0f + ex;
+    const float v = num / den;
+    p.out[(size_t)b * per_img + e] = v;
 }
 
-// ---- filter: one block (1024 threads) per image, anchors in order, stable compaction
+// ---- filter: one block (1024 threads) per image, anchors in order, stable compaction.
+// Per super-chunk of 32 x 1024 anchors: pass 1 evaluates the keep test of every anchor (independent loads, no barrier between
+// them, so their latencies overlap) and leaves one flag bit per anchor in a register and one count per (iteration, wave) in
+// LDS; one scan turns the counts into output offsets; pass 2 re-reads only the kept rows (L2-hot) and writes them.  The
+// previous form paid a global-load round trip and three barriers per 1024 anchors (23 us for 8400 anchors x 64 images).
+constexpr int F_IT = 32;
 __global__ __launch_bounds__(1024) void filter_kernel(const float* pred, int A, int nc, float conf, float* cand, int* counts) {
-    __shared__ int wsum[16];
+    __shared__ int cnt[F_IT * 16];
     __shared__ int base_s;
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nch = 5 + nc;
     const float* pb = pred + (size_t)b * A * nch;
     float* cb = cand + (size_t)b * A * 7;
     if (t == 0) base_s = 0;
-    __syncthreads();
-    for (int a0 = 0; a0 < A; a0 += 1024) {
-        const int a = a0 + t;
-        bool keep = false;
-        float x1 = 0, y1 = 0, x2 = 0, y2 = 0, obj = 0, cc = 0;
-        int cp = 0;
-        if (a < A) {
-            const float* r = pb + (size_t)a * nch;
-            const float cx = r[0], cy = r[1], w = r[2], h = r[3];
-            x1 = cx - w / 2; y1 = cy - h / 2; x2 = cx + w / 2; y2 = cy + h / 2;
-            obj = r[4];
-            cc = r[5];
-            for (int c = 1; c < nc; ++c) {
-                float v = r[5 + c];
-                if (v > cc) { cc = v; cp = c; }  // strict >: first maximal index on ties (torch.max)
+    for (int s0 = 0; s0 < A; s0 += F_IT * 1024) {
+        const int iters = min(F_IT, (A - s0 + 1023) / 1024);
+        unsigned flags = 0u;
+        for (int k = 0; k < iters; ++k) {
+            const int a = s0 + k * 1024 + t;
+            bool keep = false;
+            if (a < A) {
+                const float* r = pb + (size_t)a * nch;
+                const float obj = r[4];
+                float cc = r[5];
+                for (int c = 1; c < nc; ++c) {  // the value of the maximum, by the same comparisons as pass 2 (its index is found there)
+                    const float v = r[5 + c];
+                    if (v > cc) cc = v;
+                }
+                keep = (obj * cc) >= conf;
             }
-            keep = (obj * cc) >= conf;
-        }
-        const unsigned long long bal = __ballot(keep);
-        const int within = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wave] = __popcll(bal);
-        __syncthreads();
-        int off = base_s;
-        for (int q = 0; q < wave; ++q) off += wsum[q];
-        if (keep) {
-            float* d = cb + (size_t)(off + within) * 7;
-            d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2; d[4] = obj; d[5] = cc; d[6] = (float)cp;
+            flags |= keep ? (1u << k) : 0u;
+            const unsigned long long bal = __ballot(keep);
+            if (lane == 0) cnt[k * 16 + wave] = __popcll(bal);
         }
         __syncthreads();
-        if (t == 0) {
-            int tot = 0;
-            for (int q = 0; q < 16; ++q) tot += wsum[q];
-            base_s += tot;
+        // exclusive scan of cnt in (iteration, wave) order = anchor order; 512 entries at most, one wave does it
+        if (t < 64) {
+            int carry = base_s;
+            for (int i0 = 0; i0 < iters * 16; i0 += 64) {
+                const int i = i0 + t;
+                const int v = i < iters * 16 ? cnt[i] : 0;
+                int incl = v;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int u = __shfl_up(incl, o, 64);
+                    if (t >= o) incl += u;
+                }
+                if (i < iters * 16) cnt[i] = carry + incl - v;
+                carry += __shfl(incl, 63, 64);
+            }
+            if (t == 0) base_s = carry;
         }
         __syncthreads();
+        for (int k = 0; k < iters; ++k) {
+            const bool keep = (flags >> k) & 1u;
+            const unsigned long long bal = __ballot(keep);
+            if (keep) {
+                const int a = s0 + k * 1024 + t;
+                const float* r = pb + (size_t)a * nch;
+                const float cx = r[0], cy = r[1], w = r[2], h = r[3];
+                float cc = r[5];
+                int cp = 0;
+                for (int c = 1; c < nc; ++c) {
+                    const float v = r[5 + c];
+                    if (v > cc) { cc = v; cp = c; }  // strict >: first maximal index on ties (torch.max)
+                }
+                float* d = cb + (size_t)(cnt[k * 16 + wave] + __popcll(bal & ((1ull << lane) - 1ull))) * 7;
+                d[0] = cx - w / 2; d[1] = cy - h / 2; d[2] = cx + w / 2; d[3] = cy + h / 2; d[4] = r[4]; d[5] = cc; d[6] = (float)cp;
+            }
+        }
+        __syncthreads();  // cnt is rewritten by the next super-chunk
     }
     if (t == 0) counts[b] = base_s;
 }
@@ -110,6 +141,14 @@ NmsWs nms_ws(int B, int nmax) {
     w.mask = (w.mask + 255) & ~(size_t)255;
     w.total = w.mask + (size_t)B * np * w.W * 8;         // u64 [B][np][W]
     return w;
+}
+
+// word held by lane j (j wave-uniform) as a scalar: two v_readlane_b32 instead of two ds_bpermute round trips -- the greedy
+// sweep reads 64 of them in a dependent loop, and the LDS latency of the shuffles was most of its time
+__device__ __forceinline__ unsigned long long lane_word(unsigned long long v, int j) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, j);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), j);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 // torchvision nms: areas and the intersection in fp32, ovr = inter / (area_i + area_j - inter) compared as a double against
@@ -238,7 +277,7 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const int* counts, int n
             unsigned long long kept = 0ull;
             const int jn = min(64, n - c * 64);
             for (int j = 0; j < jn; ++j) {
-                const unsigned long long dj = __shfl(diag, j, 64);
+                const unsigned long long dj = lane_word(diag, j);
                 if (!((rem >> j) & 1ull)) {
                     kept |= 1ull << j;
                     rem |= dj;
@@ -290,11 +329,17 @@ __global__ __launch_bounds__(256) void nms_gather_kernel(const float* cand, int 
 }
 
 // ---- the whole NMS of one image in ONE block, for nmax <= SMALL_NMAX candidates per image: prepare, rank, mask, sweep and
-// gather as above, with the offset boxes, the sorted boxes, the order and the pair bitmask in LDS (52 KB) instead of the
+// gather as above, with the offset boxes, the sorted boxes, the order and the pair bitmask in LDS instead of the
 // workspace.  Five dependent launches of microsecond kernels become one; the arithmetic is the same device functions.
-constexpr int SMALL_NMAX = 512, SMALL_W = SMALL_NMAX / 64;
+constexpr int SMALL_NMAX = 256, SMALL_W = SMALL_NMAX / 64, SMALL_T = 512;  // beyond this the tiled kernels' many blocks win
 
-__global__ __launch_bounds__(256) void nms_small_kernel(const float* cand, const int* counts, int A, int nmax, double thr, const int* image_hw, float* det,
+#ifdef NMS_STAMP  // diagnostic build: cycles per phase of block 0 (0 prepare, 1 rank, 2 mask, 3 sweep, 4 gather)
+__device__ unsigned long long g_nms_stamps[8];
+#define NSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_nms_stamps[i], n_ - st_last); st_last = n_; } } while (0)
+#else
+#define NSTAMP(i)
+#endif
+__global__ __launch_bounds__(SMALL_T) void nms_small_kernel(const float* cand, const int* counts, int A, int nmax, double thr, const int* image_hw, float* det,
                                                         int* keep_idx, int* nkeep) {
     __shared__ float4 boxes[SMALL_NMAX];
     __shared__ float4 sboxes[SMALL_NMAX];
@@ -302,91 +347,121 @@ __global__ __launch_bounds__(256) void nms_small_kernel(const float* cand, const
     __shared__ int order[SMALL_NMAX];
     __shared__ int kept_s[SMALL_NMAX];  // candidate indices of the kept boxes, score order
     __shared__ unsigned long long mask[SMALL_NMAX * SMALL_W];
-    __shared__ float red[4];
+    __shared__ float red[SMALL_T / 64];
     __shared__ float maxc_s;
     __shared__ int total_s;
+    __shared__ unsigned long long removed_s[SMALL_W];
+#ifdef NMS_STAMP
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
     const int b = blockIdx.x, t = threadIdx.x;
     const int n = min(min(counts[b], nmax), SMALL_NMAX);
     const int nw = (n + 63) / 64;
     const float* cb = cand + (size_t)b * A * 7;
     // prepare
     float m = -INFINITY;
-    for (int i = t; i < n; i += 256) {
+    for (int i = t; i < n; i += SMALL_T) {
         const float* r = cb + (size_t)i * 7;
         m = fmaxf(m, fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])));
     }
     m = wave_max(m);
     if ((t & 63) == 0) red[t >> 6] = m;
     __syncthreads();
-    if (t == 0) maxc_s = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (t == 0) {
+        float mm = red[0];
+        for (int q = 1; q < SMALL_T / 64; ++q) mm = fmaxf(mm, red[q]);
+        maxc_s = mm;
+    }
     __syncthreads();
     const float step = maxc_s + 1.0f;
-    for (int i = t; i < n; i += 256) {
+    for (int i = t; i < n; i += SMALL_T) {
         const float* r = cb + (size_t)i * 7;
         const float off = r[6] * step;
         boxes[i] = make_float4(r[0] + off, r[1] + off, r[2] + off, r[3] + off);
         scores[i] = r[4] * r[5];
     }
     __syncthreads();
-    // stable descending rank
-    for (int i = t; i < n; i += 256) {
-        const float si = scores[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const float sj = scores[j];
-            rank += (sj > si || (sj == si && j < i)) ? 1 : 0;
+    NSTAMP(0);
+    // stable descending rank: one wave per box, lanes over the other boxes (a thread per box would walk n LDS reads in a row)
+    const int lane = t & 63, wave = t >> 6;
+    // (four boxes / four (row, word) items per wave at a time: each item is a long dependent chain -- LDS read, IEEE division,
+    // ballot -- and independent chains side by side are what hides its latency)
+    constexpr int NWV = SMALL_T / 64, UNR = 4;
+    for (int i0 = wave * UNR; i0 < n; i0 += NWV * UNR) {
+        float si[UNR];
+        int rank[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            si[u] = scores[min(i0 + u, n - 1)];
+            rank[u] = 0;
         }
-        order[rank] = i;
-        sboxes[rank] = boxes[i];
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            const float sj = j < n ? scores[j] : -INFINITY;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) rank[u] += __popcll(__ballot(j < n && (sj > si[u] || (sj == si[u] && j < i0 + u))));
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (lane == 0 && i0 + u < n) {
+                order[rank[u]] = i0 + u;
+                sboxes[rank[u]] = boxes[i0 + u];
+            }
     }
     __syncthreads();
-    // pair bitmask: item = (row i, word w), only words at or after the row's own
-    for (int it = t; it < n * nw; it += 256) {
-        const int i = it / nw, w = it - i * nw;
-        unsigned long long bits = 0ull;
-        if (w >= (i >> 6)) {
+    NSTAMP(1);
+    // pair bitmask: one wave per (row i, word w >= the row's own), one pair per lane -- the IoU's IEEE division is ~40 VALU
+    // instructions, and a thread per row would run 64 of them back to back
+    const int items = n * nw;
+    for (int it0 = wave * UNR; it0 < items; it0 += NWV * UNR) {
+        unsigned long long bits[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int it = min(it0 + u, items - 1);
+            const int i = it / nw, w = it - i * nw;
             const float4 bi = sboxes[i];
             const float ai = (bi.z - bi.x) * (bi.w - bi.y);
-            const int j0 = w * 64, jn = min(64, n - j0);
-            for (int j = 0; j < jn; ++j)
-                if (j0 + j > i && suppresses(bi, ai, sboxes[j0 + j], thr)) bits |= 1ull << j;
+            const int j = w * 64 + lane;
+            const bool hit = j < n && j > i && suppresses(bi, ai, sboxes[min(j, n - 1)], thr);
+            bits[u] = __ballot(hit);
         }
-        mask[i * SMALL_W + w] = bits;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (lane == 0 && it0 + u < items) mask[((it0 + u) / nw) * SMALL_W + (it0 + u) % nw] = bits[u];
     }
     __syncthreads();
-    // greedy sweep by wave 0, 64 sorted boxes at a time
+    NSTAMP(2);
+    // greedy sweep by wave 0, 64 sorted boxes at a time.  Everything the inner loop touches is wave-uniform and is kept in
+    // scalar registers on purpose (readfirstlane / readlane): as vector code the 64 dependent iterations of shifts, tests and
+    // ORs cost four cycles per instruction and took 27 of this kernel's 33 us.  Rows of kept boxes reach the words ahead
+    // through LDS atomics (one wave: LDS executes its instructions in order, so the next chunk's read sees them).
     if (t < 64) {
-        unsigned long long removed[SMALL_W];
-#pragma unroll
-        for (int w = 0; w < SMALL_W; ++w) removed[w] = 0ull;
+        volatile unsigned long long* rm = removed_s;
+        if (t < SMALL_W) rm[t] = 0ull;
         int total = 0;
-#pragma unroll
-        for (int c = 0; c < SMALL_W; ++c) {
-            if (c < nw) {
-                const int i = c * 64 + t;
-                const unsigned long long diag = i < n ? mask[i * SMALL_W + c] : 0ull;
-                unsigned long long rem = removed[c];
-                unsigned long long kept = 0ull;
-                const int jn = min(64, n - c * 64);
-                for (int j = 0; j < jn; ++j) {
-                    const unsigned long long dj = __shfl(diag, j, 64);
-                    if (!((rem >> j) & 1ull)) {
-                        kept |= 1ull << j;
-                        rem |= dj;
-                    }
-                }
-                const bool mine = (kept >> t) & 1ull;
-                if (mine) kept_s[total + __popcll(kept & ((1ull << t) - 1ull))] = order[i];
-                total += __popcll(kept);
-                // OR the rows of the kept boxes into the words ahead (every lane ends up with the same words)
-#pragma unroll
-                for (int w = c + 1; w < SMALL_W; ++w) {
-                    unsigned long long v = (mine && w < nw) ? mask[i * SMALL_W + w] : 0ull;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
-                    removed[w] |= v;
+        for (int c = 0; c < nw; ++c) {
+            const int i = c * 64 + t;
+            const unsigned long long diag = i < n ? mask[i * SMALL_W + c] : 0ull;
+            const unsigned long long r0 = rm[c];
+            unsigned long long rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(r0 >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)r0);
+            unsigned long long kept = 0ull;
+            const int jn = min(64, n - c * 64);
+            for (int j = 0; j < jn; ++j) {
+                const unsigned long long dj = lane_word(diag, j);
+                if (!((rem >> j) & 1ull)) {
+                    kept |= 1ull << j;
+                    rem |= dj;
                 }
             }
+            const bool mine = (kept >> t) & 1ull;
+            if (mine) kept_s[total + __popcll(kept & ((1ull << t) - 1ull))] = order[i];
+            total += __popcll(kept);
+            if (mine)
+                for (int w = c + 1; w < nw; ++w) {
+                    const unsigned long long v = mask[i * SMALL_W + w];
+                    if (v) atomicOr(&removed_s[w], v);
+                }
         }
         if (t == 0) {
             nkeep[b] = total;
@@ -394,14 +469,26 @@ __global__ __launch_bounds__(256) void nms_small_kernel(const float* cand, const
         }
     }
     __syncthreads();
-    for (int k = t; k < total_s; k += 256) {
+    NSTAMP(3);
+    for (int k = t; k < total_s; k += SMALL_T) {
         const int src = kept_s[k];
         keep_idx[(size_t)b * nmax + k] = src;
         write_det(cb + (size_t)src * 7, image_hw, b, det + ((size_t)b * nmax + k) * 7);
     }
+    NSTAMP(4);
 }
 
 }  // namespace
+
+#ifdef NMS_STAMP
+extern "C" int ccnet_debug_nms_stamps(unsigned long long* out8) {
+    CC_HIP(hipDeviceSynchronize());
+    CC_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_nms_stamps), sizeof(unsigned long long) * 8));
+    unsigned long long z[8] = {0};
+    CC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_nms_stamps), z, sizeof(z)));
+    return CCNET_OK;
+}
+#endif
 
 extern "C" int ccnet_decode(const float* const* head_dev, const int64_t* sb, const int64_t* sc, const int64_t* sp, const int32_t* h, const int32_t* w,
                             int nlev, int B, int nc, float in_h, float in_w, float* out_dev, ccnet_stream stream) {
@@ -419,11 +506,11 @@ extern "C" int ccnet_decode(const float* const* head_dev, const int64_t* sb, con
     }
     p.a0[nlev] = A;
     p.nlev = nlev; p.B = B; p.A = A; p.nch = 5 + nc; p.in_h = in_h; p.in_w = in_w; p.out = out_dev;
-    CC_REQUIRE((double)B * A * (5 + nc) < 4.0e11, "decode: too many elements");
-    const unsigned blocks = (unsigned)(((long long)B * A * (5 + nc) + 255) / 256);
+    CC_REQUIRE((double)A * (5 + nc) < 2.0e9 && B <= 65535, "decode: too many elements per image or too many images");
+    const unsigned blocks = (unsigned)(((long long)A * (5 + nc) + 255) / 256);
     return ccnet_submit(
-        [p, blocks](hipStream_t st, const float*) -> int {
-            hipLaunchKernelGGL(decode_kernel, dim3(blocks), dim3(256), 0, st, p);
+        [p, blocks, B](hipStream_t st, const float*) -> int {
+            hipLaunchKernelGGL(decode_kernel, dim3(blocks, B), dim3(256), 0, st, p);
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
@@ -467,7 +554,7 @@ extern "C" int ccnet_nms(const float* cand_dev, const int32_t* counts_dev, int B
     if (nmax <= SMALL_NMAX)
         return ccnet_submit(
             [=](hipStream_t st, const float*) -> int {
-                hipLaunchKernelGGL(nms_small_kernel, dim3(B), dim3(256), 0, st, cand_dev, counts_dev, A, nmax, nms_thres, image_hw_dev, det_dev,
+                hipLaunchKernelGGL(nms_small_kernel, dim3(B), dim3(SMALL_T), 0, st, cand_dev, counts_dev, A, nmax, nms_thres, image_hw_dev, det_dev,
                                    keep_idx_dev, nkeep_dev);
                 CC_LAUNCH_CHECK();
                 return CCNET_OK;

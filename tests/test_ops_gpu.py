@@ -587,13 +587,13 @@ def test_conv2d_random_sweep():
 
 
 def test_nms_single_block_path_equals_tiled_path():
-    """ccnet_nms runs the whole NMS of an image in one block when the caller provides <= 512 rows per image and the tiled
+    """ccnet_nms runs the whole NMS of an image in one block when the caller provides <= 256 rows per image and the tiled
     five-kernel pipeline otherwise; both use the same device arithmetic and must agree bit for bit (kept indices, order, rows),
-    and with the oracle.  Cases: dense overlaps, score ties, an empty image, exactly 512 and 64-multiples of candidates."""
+    and with the oracle.  Cases: dense overlaps, score ties, an empty image, exactly 256 and 64-multiples of candidates."""
     from oracle import ccnet_oracle as orc
     from ccnet_amd.utils import bbox
     g = torch.Generator().manual_seed(5)
-    for n_per in ([0, 1, 63, 64, 65, 300, 512, 511], [128, 128, 17, 256]):
+    for n_per in ([0, 1, 63, 64, 65, 200, 256, 255], [128, 128, 17, 192]):
         B, A = len(n_per), 600
         cand = torch.zeros(B, A, 7)
         for b, n in enumerate(n_per):
@@ -608,7 +608,7 @@ def test_nms_single_block_path_equals_tiled_path():
         hw = torch.tensor([[480, 640]] * B, dtype=torch.int32).to(DEV)
         cd, ct = cand.to(DEV), counts.to(DEV)
         res = {}
-        for nmax in (max(max(n_per), 1), 600):   # <= 512: single block; 600: tiled
+        for nmax in (max(max(n_per), 1), 600):   # <= 256: single block; 600: tiled
             det, keep_idx, nkeep, _ = bbox._nms(cd, ct, nmax, 0.5, hw)
             torch.cuda.synchronize()
             nk = nkeep.cpu().numpy()
