@@ -17,7 +17,9 @@ struct DecodeP {
     const float* head[MAXLEV];
     long long sb[MAXLEV], sc[MAXLEV], sp[MAXLEV];
     int h[MAXLEV], w[MAXLEV], a0[MAXLEV + 1];
-    float stride[MAXLEV];
+    float stride[MAXLEV], rw[MAXLEV];
+    float rnch;
+    int fast;
     int nlev, B, A, nch;
     float in_h, in_w;
     float* out;
@@ -26,16 +28,19 @@ struct DecodeP {
 // one thread per output ELEMENT (anchor, channel) of image blockIdx.y: with NHWC heads both the load and the store of a wave
 // are contiguous.  Index arithmetic is 32-bit (64-bit divisions made this kernel VALU-bound: 31 us for 47 MB).
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeP p) {
-    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    // blockIdx.z = level, so every per-level quantity is a scalar; the two index divisions go through a float reciprocal
+    // when every level has fewer than 2^22 elements (two roundings of 2^-24 each keep the product inside its integer cell),
+    // not the ~30-instruction integer sequence
+    const int l = blockIdx.z, b = blockIdx.y;
+    const int wl = p.w[l];
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;      // element inside this level: r * nch + c
+    const unsigned n_l = (unsigned)(p.a0[l + 1] - p.a0[l]) * (unsigned)p.nch;
+    if (e >= n_l) return;
+    const int r = p.fast ? (int)(((float)e + 0.5f) * p.rnch) : (int)(e / (unsigned)p.nch);
+    const int c = (int)e - r * p.nch;
+    const int gy = p.fast ? (int)(((float)r + 0.5f) * p.rw[l]) : r / wl;
+    const int gx = r - gy * wl;
     const unsigned per_img = (unsigned)p.A * (unsigned)p.nch;
-    if (e >= per_img) return;
-    const int b = blockIdx.y;
-    const int a = (int)(e / (unsigned)p.nch);
-    const int c = (int)(e - (unsigned)a * (unsigned)p.nch);
-    int l = 0;
-    while (l + 1 < p.nlev && a >= p.a0[l + 1]) ++l;
-    const int r = a - p.a0[l];
-    const int gy = r / p.w[l], gx = r - gy * p.w[l];
     const float raw = p.head[l][(long long)b * p.sb[l] + (long long)r * p.sp[l] + (long long)c * p.sc[l]];
     const float s = p.stride[l];
     // ((raw + grid) * stride) / dim, (exp(raw) * stride) / dim, 1 / (1 + exp(-raw)): same operations on the same operands as
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeP p) {
     const float num = is_xy ? (raw + g) * s : (is_box ? ex * s : 1.0f);
     const float den = is_box ? ((c & 1) ? p.in_h : p.in_w) : 1.0f + ex;
     const float v = num / den;
-    p.out[(size_t)b * per_img + e] = v;
+    p.out[(size_t)b * per_img + (unsigned)p.a0[l] * (unsigned)p.nch + e] = v;
 }
 
 // ---- filter: one block (1024 threads) per image, anchors in order, stable compaction.
@@ -507,10 +512,18 @@ extern "C" int ccnet_decode(const float* const* head_dev, const int64_t* sb, con
     p.a0[nlev] = A;
     p.nlev = nlev; p.B = B; p.A = A; p.nch = 5 + nc; p.in_h = in_h; p.in_w = in_w; p.out = out_dev;
     CC_REQUIRE((double)A * (5 + nc) < 2.0e9 && B <= 65535, "decode: too many elements per image or too many images");
-    const unsigned blocks = (unsigned)(((long long)A * (5 + nc) + 255) / 256);
+    long long biggest = 0;
+    for (int l = 0; l < nlev; ++l) {
+        p.rw[l] = 1.0f / (float)w[l];
+        const long long n_l = (long long)h[l] * w[l] * (5 + nc);
+        biggest = n_l > biggest ? n_l : biggest;
+    }
+    p.rnch = 1.0f / (float)(5 + nc);
+    p.fast = biggest < (1ll << 22) ? 1 : 0;
+    const unsigned blocks = (unsigned)((biggest + 255) / 256);
     return ccnet_submit(
-        [p, blocks, B](hipStream_t st, const float*) -> int {
-            hipLaunchKernelGGL(decode_kernel, dim3(blocks, B), dim3(256), 0, st, p);
+        [p, blocks, B, nlev](hipStream_t st, const float*) -> int {
+            hipLaunchKernelGGL(decode_kernel, dim3(blocks, B, nlev), dim3(256), 0, st, p);
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
