@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void nms_gather_kernel(const float* cand, int 
 // ---- the whole NMS of one image in ONE block, for nmax <= SMALL_NMAX candidates per image: prepare, rank, mask, sweep and
 // gather as above, with the offset boxes, the sorted boxes, the order and the pair bitmask in LDS instead of the
 // workspace.  Five dependent launches of microsecond kernels become one; the arithmetic is the same device functions.
-constexpr int SMALL_NMAX = 256, SMALL_W = SMALL_NMAX / 64, SMALL_T = 512;  // beyond this the tiled kernels' many blocks win
+constexpr int SMALL_NMAX = 256, SMALL_W = SMALL_NMAX / 64, SMALL_T = 1024;  // beyond this the tiled kernels' many blocks win
 
 #ifdef NMS_STAMP  // diagnostic build: cycles per phase of block 0 (0 prepare, 1 rank, 2 mask, 3 sweep, 4 gather)
 __device__ unsigned long long g_nms_stamps[8];
