@@ -1,6 +1,7 @@
 """nn.Module front of the MI355X path: same constructor, state_dict and forward contract as the reference's Net
 classes (network/net.py:16-23,194-275), with forward executed as one recorded libccnet_hip plan."""
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -23,6 +24,10 @@ class NetBase(nn.Module):
         self._version = 0
         self.precision = os.environ.get("CCNET_PRECISION", "bf16")
         self.alias_outputs = False  # True: return views of the plan's own head buffers (overwritten by the next call)
+        # one forward at a time per instance: the plan's buffers are shared, and a second thread's launches between this
+        # thread's launches and its copy of the outputs would hand it the other thread's results (the socket server keeps
+        # one loaded model for all request threads)
+        self._fwd_lock = threading.Lock()
         self.eval()
 
     # ---- weights changed -> recorded plans hold stale packed copies
@@ -72,8 +77,20 @@ class NetBase(nn.Module):
             raise RuntimeError("ccnet_amd Net runs on the GPU only (libccnet_hip has no CPU path); move the input to 'cuda'")
         x = x.float().contiguous()
         B, _, H, W = x.shape
-        plan, heads, _ = self.plan_for(B, H, W, x.device)
-        with torch.cuda.device(x.device):
-            plan.run(x)
-        outs = [h.permute(0, 3, 1, 2) for h in heads]
-        return outs if self.alias_outputs else [o.clone(memory_format=torch.preserve_format) for o in outs]
+        with self._fwd_lock:
+            plan, heads, _ = self.plan_for(B, H, W, x.device)
+            with torch.cuda.device(x.device):
+                plan.run(x)
+            outs = [h.permute(0, 3, 1, 2) for h in heads]
+            return outs if self.alias_outputs else [o.clone(memory_format=torch.preserve_format) for o in outs]
+
+    # copies / pickles of the module carry weights, not compiled plans or the lock
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_plans"] = {}
+        d.pop("_fwd_lock", None)
+        return d
+
+    def __setstate__(self, d):
+        super().__setstate__(d)
+        self._fwd_lock = threading.Lock()

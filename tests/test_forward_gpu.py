@@ -376,3 +376,37 @@ def test_odd_batches_and_non_square_inputs_all_nets():
     spec.loader.exec_module(mod)
     cases = [("net", 3, 96, 160), ("net_old", 2, 128, 96), ("net_deploy", 7, 64, 96), ("net_amff", 3, 64, 160), ("net_small_target", 3, 96, 64)]
     assert mod.run(cases, verbose=False) < 1e-3
+
+
+def test_one_model_shared_by_request_threads():
+    """tools/socket2springboot.py serves every connection on its own thread (:146-151); here the loaded model is kept and shared,
+    so concurrent forwards of ONE instance must not see each other's results (the plan's buffers are shared: forward is
+    serialised per instance up to the copy of its outputs).  Each thread checks every result against the single-threaded one."""
+    import threading
+    from ccnet_amd import synth
+    from ccnet_amd.utils import bbox
+    net = _model("net_deploy", 0.33, 0.5, 6, "bf16")
+    xs = [synth.synth_images(2, 224, 224, seed=70 + i).to("cuda") for i in range(4)]
+    info = [[0, 300, 200], [1, 224, 224]]
+    ref = []
+    for x in xs:
+        o = net(x)
+        ref.append(([t.clone() for t in o], bbox.post_process(bbox.decode_outputs(o, [224, 224]), 6, [224, 224], info, 0.3, 0.6)))
+    errors = []
+
+    def worker(k):
+        try:
+            for it in range(25):
+                o = net(xs[k])
+                d = bbox.post_process(bbox.decode_outputs(o, [224, 224]), 6, [224, 224], info, 0.3, 0.6)
+                if not all(torch.equal(a, b) for a, b in zip(o, ref[k][0])) or not all(np.array_equal(a, b) for a, b in zip(d, ref[k][1])):
+                    errors.append((k, it))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(120)
+    assert not errors, errors[:5]
