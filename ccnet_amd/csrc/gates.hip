@@ -68,14 +68,14 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const unsigned char* 
 }
 
 // one block per image; dynamic LDS: avg[C] max[C] hid[2*Cr]
-__global__ __launch_bounds__(256) void cbam_mlp_kernel(const float* partial, int nchunk, int C, int Cr, int HW, const float* fc1, const float* fc2,
+__global__ __launch_bounds__(1024) void cbam_mlp_kernel(const float* partial, int nchunk, int C, int Cr, int HW, const float* fc1, const float* fc2,
                                                        float* ca) {
     extern __shared__ float sm[];
     float* avg = sm;
     float* mx = sm + C;
     float* hid = sm + 2 * C;
-    const int b = blockIdx.x, t = threadIdx.x;
-    for (int c = t; c < C; c += 256) {
+    const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;  // 256 or 1024 threads: one pass over the hidden units at C = 512
+    for (int c = t; c < C; c += nt) {
         float s = 0.0f, m = -INFINITY;
 #pragma unroll 8
         for (int k = 0; k < nchunk; ++k) {
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void cbam_mlp_kernel(const float* partial, int
     __syncthreads();
     const int lane = t & 63, wave = t >> 6;
     // hidden unit j (< Cr: on the average, >= Cr: on the maximum); 8 units per wave pass so that 8 rows of fc1 are in flight
-    for (int j0 = wave * 8; j0 < 2 * Cr; j0 += 32) {
+    for (int j0 = wave * 8; j0 < 2 * Cr; j0 += (nt >> 6) * 8) {
         float a[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) a[u] = 0.0f;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void cbam_mlp_kernel(const float* partial, int
         }
     }
     __syncthreads();
-    for (int c = t; c < C; c += 256) {
+    for (int c = t; c < C; c += nt) {
         const float* wr = fc2 + (size_t)c * Cr;
         float a = 0.0f, m = 0.0f;
         if ((Cr & 3) == 0) {  // rows of fc2 are 16-byte aligned then
@@ -312,15 +312,16 @@ extern "C" int ccnet_cbam(ccnet_slice in, int dtype, int B, int H, int W, const 
             const unsigned char* ip = (const unsigned char*)in.ptr;
             unsigned char* op = (unsigned char*)out.ptr;
             size_t mlp_lds = (size_t)(2 * C + 2 * Cr) * sizeof(float);
+            const int mlp_threads = 2 * Cr >= 64 ? 1024 : 256;  // 8 hidden units per wave pass
             if (dtype == CCNET_BF16) {
                 hipLaunchKernelGGL(pool_partial_kernel<__bf16>, dim3(gs.nchunk, B), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, gs.nchunk, partial);
-                hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(256), mlp_lds, st, partial, gs.nchunk, C, Cr, HW, fc1, fc2, ca);
+                hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(mlp_threads), mlp_lds, st, partial, gs.nchunk, C, Cr, HW, fc1, fc2, ca);
                 hipLaunchKernelGGL(cbam_stats_kernel<__bf16>, dim3(pblocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, npix, LP, ca, stats);
                 hipLaunchKernelGGL(cbam_apply_kernel<__bf16>, dim3(pblocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, H, W, npix, LP, ca, stats, w7,
                                    k7, op, out.ldc, out.coff);
             } else {
                 hipLaunchKernelGGL(pool_partial_kernel<float>, dim3(gs.nchunk, B), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, gs.nchunk, partial);
-                hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(256), mlp_lds, st, partial, gs.nchunk, C, Cr, HW, fc1, fc2, ca);
+                hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(mlp_threads), mlp_lds, st, partial, gs.nchunk, C, Cr, HW, fc1, fc2, ca);
                 hipLaunchKernelGGL(cbam_stats_kernel<float>, dim3(pblocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, npix, LP, ca, stats);
                 hipLaunchKernelGGL(cbam_apply_kernel<float>, dim3(pblocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, H, W, npix, LP, ca, stats, w7,
                                    k7, op, out.ldc, out.coff);
