@@ -202,7 +202,10 @@ int ccnet_plan_num_ops(const ccnet_plan* plan);
  * into lane 0 before ccnet_plan_end().  Used for the independent head levels / PAN branches (network/net.py:225-275). */
 int ccnet_plan_set_lane(int lane);
 int ccnet_plan_wait(int dst_lane, int src_lane);
-/* x_dev, if not NULL, replaces the image pointer of every recorded ccnet_stem_conv */
+/* x_dev, if not NULL, replaces the image pointer of every recorded ccnet_stem_conv.  Lane 0 ops go to `stream`, side-lane ops
+ * to streams owned by the plan, joined back into `stream` before the call returns (nothing synchronises the host).
+ * Environment: CCNET_LANES=0 runs everything on `stream`; CCNET_GRAPH=1 replays the plan as a HIP graph from the second
+ * call with the same x_dev.  One thread at a time per plan (the library serialises concurrent callers of one plan). */
 int ccnet_plan_run(const ccnet_plan* plan, const float* x_dev, ccnet_stream stream);
 void ccnet_plan_destroy(ccnet_plan* plan);
 /* Measurement aids (bench.py): what op i is and its algorithmic work (flops = 2*MAC; bytes = every distinct input and
