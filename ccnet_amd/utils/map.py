@@ -78,3 +78,38 @@ def map_50_95(gt, dets, num_classes):
     """COCO-style mean over IoU 0.50:0.05:0.95 of the VOC mAP (tools/eval.py:186 sweeps the same thresholds)."""
     vals = [average_precision(gt, dets, num_classes, t)[0] for t in (0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9, 0.95)]
     return float(np.mean(vals)), vals
+
+
+def match_boxes(ref, got, iou_thr=0.9):
+    """Box-level agreement of two post_process outputs (lists over images of (n,7) rows [top,left,bottom,right,obj,cls_conf,cls]):
+    each reference row is matched greedily (best IoU first come, a `got` row is used once) to a row of the same image and
+    class.  Returns dict(n_ref, n_got, matched = reference rows with a same-class partner at IoU >= iou_thr, mean_iou of the
+    matched pairs, max_score_diff over the matched pairs).  The bf16 detection-level gate (tests/test_bf16_gate_gpu.py)."""
+    n_ref = n_got = matched = 0
+    ious, sdiff = [], 0.0
+    for a, b in zip(ref, got):
+        a = np.zeros((0, 7), np.float32) if a is None else np.asarray(a, dtype=np.float64)
+        b = np.zeros((0, 7), np.float32) if b is None else np.asarray(b, dtype=np.float64)
+        n_ref += a.shape[0]
+        n_got += b.shape[0]
+        if a.shape[0] == 0 or b.shape[0] == 0:
+            continue
+        t = np.maximum(a[:, None, 0], b[None, :, 0]); l = np.maximum(a[:, None, 1], b[None, :, 1])
+        bo = np.minimum(a[:, None, 2], b[None, :, 2]); r = np.minimum(a[:, None, 3], b[None, :, 3])
+        inter = np.clip(bo - t, 0, None) * np.clip(r - l, 0, None)
+        area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+        area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            iou = inter / (area_a[:, None] + area_b[None, :] - inter)
+        iou = np.where(a[:, None, 6] == b[None, :, 6], np.nan_to_num(iou), -1.0)
+        used = np.zeros(b.shape[0], bool)
+        for i in range(a.shape[0]):
+            row = np.where(used, -1.0, iou[i])
+            j = int(row.argmax())
+            if row[j] >= iou_thr:
+                used[j] = True
+                matched += 1
+                ious.append(float(row[j]))
+                sdiff = max(sdiff, abs(a[i, 4] * a[i, 5] - b[j, 4] * b[j, 5]))
+    return {"n_ref": n_ref, "n_got": n_got, "matched": matched, "mean_iou": float(np.mean(ious)) if ious else 0.0,
+            "max_score_diff": float(sdiff)}

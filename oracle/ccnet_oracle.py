@@ -49,7 +49,19 @@ def activation(name):
 
 
 # ----------------------------------------------------------------------------- blocks
+_CALIBRATE = None  # dict: while set, _bn records batch statistics into it (calibrate_bn below)
+
+
 def _bn(sd, p, x):
+    if _CALIBRATE is not None:
+        # what one train-mode forward with momentum 1.0 leaves in the running statistics (oracle/make_golden.py:calibrate_bn):
+        # batch mean and UNBIASED batch variance; the forward itself continues with the batch statistics
+        mean = x.mean((0, 2, 3))
+        n = x.numel() // x.shape[1]
+        var_b = x.var((0, 2, 3), unbiased=False)
+        _CALIBRATE[p + ".running_mean"] = mean.clone()
+        _CALIBRATE[p + ".running_var"] = var_b * (n / max(n - 1, 1))
+        return F.batch_norm(x, mean, var_b, sd[p + ".weight"], sd[p + ".bias"], False, 0.0, _BN_EPS)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
                         False, 0.0, _BN_EPS)
 
@@ -303,6 +315,25 @@ def forward(kind, sd, x, depth=1.0, width=1.0, act="silu", taps=None):
         tap("pan_out2", p2), tap("pan_out1", p1), tap("pan_out0", p0)
         feats = (p3, p2, p1, p0) if kind == "net_small_target" else (p2, p1, p0)
         return head(sd, feats, a)
+
+
+def calibrate_bn(kind, sd, x, depth=1.0, width=1.0, act="silu"):
+    """BN running statistics that keep activations O(1) for an arbitrary synthetic weight recipe: one forward
+    with batch statistics on `x`; returns a copy of `sd` with every running_mean / running_var replaced.  The committed
+    tests/golden/bn_calib_<kind>.npz files were made the same way with the REAL reference (oracle/make_golden.py); this
+    restatement serves recipes that have no committed calibration (scripts/bf16_gate.py's BN_BIAS_MEAN = 0 arm)."""
+    global _CALIBRATE
+    _CALIBRATE = {}
+    try:
+        forward(kind, sd, x, depth, width, act)
+        stats = _CALIBRATE
+    finally:
+        _CALIBRATE = None
+    out = dict(sd)
+    for k, v in stats.items():
+        assert k in out and out[k].shape == v.shape, k
+        out[k] = v
+    return out
 
 
 # ----------------------------------------------------------------------------- decode

@@ -69,6 +69,35 @@ def test_bf16_head_logits_close(name):
         assert emax < 0.15 and erms < 0.08, "level %d: max %.2e rms %.2e" % (k, emax, erms)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", FIXTURES)
+def test_intermediate_taps_match_reference_fixture(name, precision):
+    """The tap_* arrays of the fixtures (stem, dark3, dark5, gate3, pan_out1 of the REAL reference, every 3rd channel and
+    2nd pixel; oracle/make_golden.py) against the plan's own intermediate buffers (`plan.taps`): fp32 <= 1e-3 relative,
+    bf16 rms < 8 % per tap (net_amff's ASFF outputs measure 6.3 %, the CBAM nets 4-5 %).  Localises a logit mismatch to a stage."""
+    from ccnet_amd import synth
+    fx = _fixture(name)
+    tap_keys = [k for k in fx if k.startswith("tap_")]
+    if not tap_keys:
+        pytest.skip("fixture carries no taps")
+    kind, B, H, W = str(fx["kind"]), int(fx["B"]), int(fx["H"]), int(fx["W"])
+    net = _model(kind, float(fx["depth"]), float(fx["width"]), int(fx["nc"]), precision)
+    net(synth.synth_images(B, H, W, seed=0).to("cuda"))
+    torch.cuda.synchronize()
+    plan = net.plan_for(B, H, W, torch.device("cuda", torch.cuda.current_device()))[0]
+    for key in tap_keys:
+        t = plan.taps[key[4:]]
+        got = t.buf[..., t.coff:t.coff + t.C].float().cpu().permute(0, 3, 1, 2)[:, ::3, ::2, ::2]
+        ref = torch.from_numpy(fx[key])
+        assert got.shape == ref.shape, key
+        if precision == "fp32":
+            err = float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
+            assert err < 1e-3, "%s: rel err %.2e" % (key, err)
+        else:
+            rms = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-12))
+            assert rms < 0.08, "%s: bf16 rms %.3e" % (key, rms)
+
+
 @pytest.mark.parametrize("name", FIXTURES)
 def test_decode_and_post_process_on_reference_logits(name):
     """Feed the reference's own logits: decode within fp32 tolerance; post_process on the reference's decoded tensor
