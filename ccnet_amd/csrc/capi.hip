@@ -165,22 +165,25 @@ int run_eager(ccnet_plan* plan, const float* x_dev, hipStream_t st, bool lanes) 
         if (rc != CCNET_OK) return rc;
     }
     size_t wi = 0;
+    int rc = CCNET_OK;  // after a failed launch the remaining ops are skipped but the recorded forks / joins are still
+                        // emitted, so the side lanes are joined back into `st` (and a capture is closed) whatever happened
     for (const auto& op : plan->ops) {
         if (op.wait_src >= 0) {
             if (r) {
                 hipStream_t src = op.wait_src == 0 ? st : r->side[op.wait_src - 1];
                 hipStream_t dst = op.lane == 0 ? st : r->side[op.lane - 1];
-                CC_HIP(hipEventRecord(r->events[wi], src));
-                CC_HIP(hipStreamWaitEvent(dst, r->events[wi], 0));
+                if (hipEventRecord(r->events[wi], src) != hipSuccess || hipStreamWaitEvent(dst, r->events[wi], 0) != hipSuccess) {
+                    if (rc == CCNET_OK) rc = ccnet_set_error(CCNET_EHIP, "plan_run: event record / stream wait failed");
+                }
             }
             ++wi;
             continue;
         }
+        if (rc != CCNET_OK) continue;
         hipStream_t s = (r && op.lane > 0) ? r->side[op.lane - 1] : st;
-        int rc = op.fn(s, x_dev);
-        if (rc != CCNET_OK) return rc;
+        rc = op.fn(s, x_dev);
     }
-    return CCNET_OK;
+    return rc;
 }
 bool graphs_enabled() {
     static int v = -1;

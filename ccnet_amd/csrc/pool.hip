@@ -94,6 +94,33 @@ __global__ __launch_bounds__(256) void sppf_kernel(unsigned char* buf, int ldc, 
     }
 }
 
+// Fallback for planes that do not fit in LDS (H*W > 5120, i.e. inputs beyond ~2290 px per side): one cascade level per launch,
+// y_level = MaxPool2d(5,1,2)(y_{level-1}) read straight from global memory (25 taps, neighbours hit L1/L2).  Same values as
+// the LDS kernel (max is exact); three launches instead of one.
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_level_kernel(unsigned char* buf, int ldc, int coff, int C, int B, int H, int W, int level) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int G = C / EPC;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * H * W * G;
+    if (idx >= total) return;
+    const int g = (int)(idx % G);
+    const long long pix = idx / G;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const long long b = pix / ((long long)W * H);
+    const size_t src_c = (size_t)coff + (size_t)(level - 1) * C + (size_t)g * EPC;
+    uint4 m = *(const uint4*)(buf + ((size_t)pix * ldc + src_c) * sizeof(T));
+    for (int dy = -2; dy <= 2; ++dy) {
+        if ((unsigned)(y + dy) >= (unsigned)H) continue;
+        for (int dx = -2; dx <= 2; ++dx) {
+            if ((unsigned)(x + dx) >= (unsigned)W || (dx == 0 && dy == 0)) continue;
+            const size_t q = ((size_t)b * H + (y + dy)) * W + (x + dx);
+            m = Vec16<T>::vmax(m, *(const uint4*)(buf + (q * ldc + src_c) * sizeof(T)));
+        }
+    }
+    *(uint4*)(buf + ((size_t)pix * ldc + src_c + C) * sizeof(T)) = m;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool3s2_kernel(const unsigned char* in, int in_ldc, int in_coff, int B, int H, int W, int C,
                                                          unsigned char* out, int out_ldc, int out_coff, int Ho, int Wo) {
@@ -128,8 +155,26 @@ extern "C" int ccnet_sppf_pool(ccnet_slice buf, int dtype, int B, int H, int W, 
     CC_REQUIRE(cc_dtype_ok(dtype) && cc_slice_vec_ok(buf, dtype) && buf.shift == 0, "sppf_pool: bad slice");
     CC_REQUIRE(buf.ldc >= buf.coff + 4 * buf.C, "sppf_pool: buffer must hold 4*C channels from coff (ldc=%d coff=%d C=%d)", buf.ldc, buf.coff, buf.C);
     CC_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0, "sppf_pool: bad geometry");
-    CC_REQUIRE((size_t)H * W * 32 <= 160 * 1024, "sppf_pool: %dx%d plane does not fit in LDS (max H*W = 5120)", H, W);
     const int G = buf.C / (16 / cc_esize(dtype));
+    const double sppf_bytes = 4.0 * B * H * W * (double)buf.C * cc_esize(dtype);
+    if ((size_t)H * W * 32 > 160 * 1024 - 1024) {
+        // plane too large for LDS: three global-memory passes (inputs beyond ~2290 px per side)
+        const long long total = (long long)B * H * W * G;
+        CC_REQUIRE(total < (1ll << 31) * 256, "sppf_pool: too many elements");
+        const unsigned blocks = (unsigned)((total + 255) / 256);
+        return ccnet_submit(
+            [=](hipStream_t st, const float*) -> int {
+                for (int level = 1; level <= 3; ++level) {
+                    if (dtype == CCNET_BF16)
+                        hipLaunchKernelGGL(sppf_level_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (unsigned char*)buf.ptr, buf.ldc, buf.coff, buf.C, B, H, W, level);
+                    else
+                        hipLaunchKernelGGL(sppf_level_kernel<float>, dim3(blocks), dim3(256), 0, st, (unsigned char*)buf.ptr, buf.ldc, buf.coff, buf.C, B, H, W, level);
+                    CC_LAUNCH_CHECK();
+                }
+                return CCNET_OK;
+            },
+            stream, CCNET_OP_SPPF, 0.0, sppf_bytes);
+    }
     // channel groups per block: a power of two that divides G, as many as keep a block within ~52 KB of LDS (three blocks per
     // CU), at most 8 (128 contiguous bytes per pixel)
     int lg = 0;
@@ -149,7 +194,7 @@ extern "C" int ccnet_sppf_pool(ccnet_slice buf, int dtype, int B, int H, int W, 
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
-        stream, CCNET_OP_SPPF, 0.0, 4.0 * B * H * W * (double)buf.C * cc_esize(dtype));
+        stream, CCNET_OP_SPPF, 0.0, sppf_bytes);
 }
 
 extern "C" int ccnet_maxpool3x3s2(ccnet_slice in, int dtype, int B, int H, int W, ccnet_slice out, ccnet_stream stream) {

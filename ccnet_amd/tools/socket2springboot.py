@@ -7,6 +7,7 @@ so that callers without OpenCV file access (and the tests) can use the entry poi
 (:174-215: a JSON request terminated by "over", the reply `str(dict)`, "500" on any exception) is `handle_request`;
 `ServerThreading` / `main` (:126-172) are the same thin socket loop around it.
 """
+import collections
 import json
 import os
 import socket
@@ -19,8 +20,22 @@ from ..network.net import Net
 from ..utils.util import load_model_weights
 from .demo import detections_to_annotations, predict, preprocess
 
-_models = {}
+_models = collections.OrderedDict()  # LRU, newest last
 _lock = threading.Lock()
+MAX_MODELS = max(int(os.environ.get("CCNET_MAX_MODELS", "4")), 1)
+# input_shape comes from the client: every distinct (H, W) compiles a plan with its own activation buffers, so sizes are
+# validated (multiples of 32, bounded side) before anything is allocated; Net itself keeps at most CCNET_MAX_PLANS plans
+MAX_INPUT_SIDE = int(os.environ.get("CCNET_MAX_INPUT_SIDE", "2048"))
+
+
+def check_input_shape(input_shape):
+    if (not isinstance(input_shape, (list, tuple)) or len(input_shape) != 2
+            or not all(isinstance(v, int) and not isinstance(v, bool) for v in input_shape)):
+        raise ValueError("input_shape must be [height, width] integers")
+    h, w = input_shape
+    if h < 32 or w < 32 or h % 32 or w % 32 or h > MAX_INPUT_SIDE or w > MAX_INPUT_SIDE:
+        raise ValueError("input_shape %r: sides must be multiples of 32 in [32, %d]" % (list(input_shape), MAX_INPUT_SIDE))
+    return [h, w]
 
 
 def get_classes(path):
@@ -31,16 +46,29 @@ def get_classes(path):
 
 
 def _model_for(model_path, num_classes, device):
-    key = (os.path.abspath(model_path) if model_path else None, num_classes, str(device))
+    """One loaded model per (checkpoint file, its mtime and size, num_classes, device): the reference reloads the file on
+    every request (:58-61), so a checkpoint overwritten in place must be picked up -- the stat is part of the key."""
+    path = os.path.abspath(model_path) if model_path else None
+    stamp = None
+    if path:
+        st = os.stat(path)
+        stamp = (st.st_mtime_ns, st.st_size)
+    key = (path, stamp, num_classes, str(device))
     with _lock:
         model = _models.get(key)
         if model is None:
+            for k in [k for k in _models if k[0] == path and k[2:] == key[2:]]:
+                del _models[k]  # the same file with an older stamp
+            while len(_models) >= MAX_MODELS:
+                _models.popitem(last=False)
             model = Net(depth=0.33, width=0.5, num_classes=num_classes, act="silu")  # :58
             if model_path:
                 model, _ = load_model_weights(model, model_path, device)
             model.to(device)
             model.eval()
             _models[key] = model
+        else:
+            _models.move_to_end(key)
         return model
 
 
@@ -54,6 +82,7 @@ def inference(model_name, model_path, dataset, input_shape, conf_thres, nms_thre
         root = datasets_root or os.getcwd()
         class_names, _ = get_classes(os.path.join(root, "datasets/%s/classes.txt" % dataset))
     num_classes = len(class_names)
+    input_shape = check_input_shape(input_shape)
     model = _model_for(model_path, num_classes, device)
     msg = {"image": [], "annotations": []}
     for image_id, image_path in enumerate(image_paths):

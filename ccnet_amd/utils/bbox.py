@@ -8,10 +8,15 @@ Differences a caller can observe (documented in DESIGN.md):
 NMS follows torchvision 0.9.0 `batched_nms` (coordinate trick) with a stable descending sort; keep order and
 indices are bit-exact against the oracle's scalar restatement.
 """
+import threading
+
 import numpy as np
 import torch
 
 from .. import ops
+
+# the two small caches below are shared by every request thread of the socket server
+_cache_lock = threading.Lock()
 
 
 def _require_cuda(t, what):
@@ -26,11 +31,14 @@ def _image_hw(hw, device):
     """int32 (B, 2) device tensor of (image_h, image_w); batches of a dataset mostly repeat the same sizes, so the small
     host->device copy is made once per distinct tuple (bounded cache)."""
     key = (hw, str(device))
-    t = _hw_cache.get(key)
+    with _cache_lock:
+        t = _hw_cache.get(key)
     if t is None:
-        if len(_hw_cache) >= 64:
-            _hw_cache.clear()
-        t = _hw_cache[key] = torch.tensor(hw, dtype=torch.int32).reshape(-1, 2).to(device)
+        t = torch.tensor(hw, dtype=torch.int32).reshape(-1, 2).to(device)
+        with _cache_lock:
+            if len(_hw_cache) >= 64:
+                _hw_cache.clear()
+            _hw_cache[key] = t
     return t
 
 
@@ -70,7 +78,8 @@ def _filter_and_nms(pred, num_classes, conf_thres, nms_thres, image_hw):
     dev = pred.device
     key = (B, A, str(dev))
     cand = torch.empty(B, A, 7, dtype=torch.float32, device=dev)
-    nmax = _nmax_guess.get(key)
+    with _cache_lock:
+        nmax = _nmax_guess.get(key)
     if nmax is None:
         both = None
         counts = torch.empty(B, dtype=torch.int32, device=dev)
@@ -88,9 +97,10 @@ def _filter_and_nms(pred, num_classes, conf_thres, nms_thres, image_hw):
         _nms(cand, counts, nmax, nms_thres, image_hw, both)
         host = both.cpu().numpy()
         cmax = int(host[B * nmax * 7 + B:].view(np.int32).max())
-        if len(_nmax_guess) >= 64:
-            _nmax_guess.clear()
-        _nmax_guess[key] = min(A, max(64, -(-(cmax + cmax // 4) // 64) * 64))
+        with _cache_lock:
+            if len(_nmax_guess) >= 64:
+                _nmax_guess.clear()
+            _nmax_guess[key] = min(A, max(64, -(-(cmax + cmax // 4) // 64) * 64))
         if cmax <= nmax:
             return host[:B * nmax * 7].reshape(B, nmax, 7), host[B * nmax * 7:B * nmax * 7 + B].view(np.int32)
         nmax, both = min(cmax, A), None

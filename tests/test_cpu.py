@@ -455,3 +455,64 @@ def test_product_path_fails_loudly_without_the_hip_library(tmp_path):
     env = dict(os.environ, CCNET_HIP_LIB=str(tmp_path / "nowhere" / "libccnet_hip.so"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "loud" in r.stdout, r.stdout + r.stderr
+
+
+def test_compat_shim_resolves_reference_import_lines():
+    """compat/ first on PYTHONPATH: the import lines of the reference's callers (tools/demo.py:18-21,
+    tools/socket2springboot.py:22-26, tools/eval.py:24-29) resolve to ccnet_amd without editing the caller."""
+    import subprocess
+    code = (
+        "from network.net import Net\n"
+        "from network.net_deploy import Net as D\n"
+        "from network.net_amff import Net as A\n"
+        "from network.net_small_target import Net as S\n"
+        "from network.net_old import Net as O\n"
+        "from utils.bbox import decode_outputs, post_process\n"
+        "from utils.initialization import device_initializer, model_initializer\n"
+        "from utils.util import get_classes, draw_rectangle, load_model_weights, get_root_path, get_val_lines\n"
+        "import tools.demo, tools.eval, tools.socket2springboot, utils.map\n"
+        "assert Net.__module__ == 'ccnet_amd.network.net' and D.__module__ == 'ccnet_amd.network.net_deploy'\n"
+        "assert A.__module__ == 'ccnet_amd.network.net_amff' and S.__module__ == 'ccnet_amd.network.net_small_target'\n"
+        "assert O.__module__ == 'ccnet_amd.network.net_old'\n"
+        "assert decode_outputs.__module__ == 'ccnet_amd.utils.bbox' and post_process.__module__ == 'ccnet_amd.utils.bbox'\n"
+        "assert load_model_weights.__module__ == 'ccnet_amd.utils.util' and model_initializer('s') == (0.33, 0.5)\n"
+        "assert tools.demo.inference.__module__ == 'ccnet_amd.tools.demo'\n"
+        "m = Net(0.33, 0.5, 6, 'silu'); assert len(m.state_dict()) == 639 and m.precision == 'fp32'\n"
+        "print('shim ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "compat") + os.pathsep + ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0 and "shim ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_socket_server_validates_client_sizes_and_bounds_its_caches(tmp_path):
+    """input_shape comes from the client and every distinct size compiles a plan: sizes are validated before anything is
+    allocated; the model cache is an LRU keyed by the checkpoint's path, mtime and size."""
+    import json
+    from ccnet_amd.tools import socket2springboot as s2s
+    names = ["c%d" % i for i in range(6)]
+    for bad in ([100, 100], [224], [224, 4096 * 32], [0, 224], ["224", 224], [224.0, 224], [-32, 32]):
+        with pytest.raises(ValueError):
+            s2s.check_input_shape(bad)
+        req = {"model_name": "Net", "model_path": "", "dataset": "NEUDET", "input_shape": bad, "conf_thres": 0.5, "nms_thres": 0.6, "image_path": []}
+        assert s2s.handle_request(json.dumps(req) + "over", class_names=names) == "500"
+    assert s2s.check_input_shape([224, 640]) == [224, 640]
+    # a checkpoint rewritten in place is reloaded (the reference reloads on every request, :58-61)
+    from ccnet_amd import synth
+    from ccnet_amd.network.net import Net
+    net = Net(0.33, 0.5, 6, "silu")
+    path = str(tmp_path / "w.pth")
+    sd = synth.synth_state_dict(net.state_dict(), seed=0)
+    torch.save({"epoch": 1, "model": sd, "ap50": 0.0, "ap5095": 0.0}, path)
+    s2s._models.clear()
+    m1 = s2s._model_for(path, 6, "cpu")
+    assert s2s._model_for(path, 6, "cpu") is m1
+    sd2 = synth.synth_state_dict(net.state_dict(), seed=1)
+    torch.save({"epoch": 2, "model": sd2, "ap50": 0.0, "ap5095": 0.0}, path)
+    os.utime(path, ns=(os.stat(path).st_atime_ns, os.stat(path).st_mtime_ns + 1_000_000))
+    m2 = s2s._model_for(path, 6, "cpu")
+    assert m2 is not m1 and torch.equal(m2.state_dict()["stems.0.conv.weight"], sd2["stems.0.conv.weight"])
+    assert len(s2s._models) == 1
+    for nc in range(1, s2s.MAX_MODELS + 3):
+        s2s._model_for("", nc, "cpu")
+    assert len(s2s._models) == s2s.MAX_MODELS
+    s2s._models.clear()

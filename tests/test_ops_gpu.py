@@ -202,7 +202,7 @@ def test_dwconv3x3(code):
 
 
 @pytest.mark.parametrize("code", [0, 1])
-@pytest.mark.parametrize("H,W", [(20, 20), (7, 5), (40, 40)])
+@pytest.mark.parametrize("H,W", [(20, 20), (7, 5), (40, 40), (80, 72)])  # 80x72 > 5088 pixels: the global-memory fallback
 def test_sppf_pool_exact(code, H, W):
     ops = _ops()
     g = torch.Generator().manual_seed(17)
