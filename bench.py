@@ -50,31 +50,150 @@ def build_model(kind, precision):
 
 
 def cpu_baseline(kind, size, conf, nms):
-    """Oracle (CPU port of the reference path) on a bounded sample: 1 warm-up + 2 timed passes of 4 images."""
+    """Oracle (CPU port of the reference path) on bounded samples, SURVEY 8(d): median of >= 5 passes after 2 warm-ups with all
+    the cores this process may use and again with one thread (the reference server's stated intent,
+    tools/socket2springboot.py:53-55); BASELINE configs[0] exactly (net, 224^2, bs1, conf 0.5 / nms 0.6) and the benched
+    configuration at a reduced batch scaled to images/s."""
+    import importlib
+    import platform
+    import statistics
     from ccnet_amd import synth
     from oracle import ccnet_oracle as orc
-    import importlib
-    net = importlib.import_module("ccnet_amd.network." + kind).Net(0.33, 0.5, 6, "silu")
-    sd = synth.synth_state_dict(net.state_dict(), seed=0, bn_calib=kind)
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(threads)
-    bs = 4
-    x = synth.synth_images(bs, size, size, seed=0)
-    info = [[i, size, size] for i in range(bs)]
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
 
-    def once():
-        heads = orc.forward(kind, sd, x, 0.33, 0.5, "silu")
-        dec = orc.decode_outputs(heads, [size, size])
-        return orc.post_process(dec, 6, [size, size], info, conf, nms)
+    def measure(knd, sz, bs, threads, warm, reps, cf, nm):
+        net = importlib.import_module("ccnet_amd.network." + knd).Net(0.33, 0.5, 6, "silu")
+        sd = synth.synth_state_dict(net.state_dict(), seed=0, bn_calib=knd)
+        torch.set_num_threads(threads)
+        x = synth.synth_images(bs, sz, sz, seed=0)
+        info = [[i, sz, sz] for i in range(bs)]
+        ts = []
+        for i in range(warm + reps):
+            t0 = time.perf_counter()
+            heads = orc.forward(knd, sd, x, 0.33, 0.5, "silu")
+            dec = orc.decode_outputs(heads, [sz, sz])
+            orc.post_process(dec, 6, [sz, sz], info, cf, nm)
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+        return round(bs / statistics.median(ts), 3)
 
-    once()
-    t0 = time.perf_counter()
-    reps = 2
+    cpu_model = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    all_cores = measure(kind, size, 8, cores, 2, 5, conf, nms)
+    one = measure(kind, size, 2, 1, 1, 3, conf, nms)
+    c1_all = measure("net", 224, 1, cores, 2, 7, 0.5, 0.6)
+    c1_one = measure("net", 224, 1, 1, 2, 7, 0.5, 0.6)
+    torch.set_num_threads(cores)
+    return {"value": all_cores, "unit": "images/s", "cores": cores, "kind": "port", "cpu": cpu_model,
+            "sample": "%s %dx%d bs8 fp32 fwd+decode+NMS (conf %.3g, nms %.3g), median of 5 passes after 2 warm-ups, torch CPU oracle, %d threads"
+                      % (kind, size, size, conf, nms, cores),
+            "one_thread": {"value": one, "unit": "images/s", "cores": 1,
+                           "sample": "%s %dx%d bs2, median of 3 passes after 1 warm-up, 1 thread" % (kind, size, size)},
+            "config1_net_224_bs1": {"value": c1_all, "unit": "images/s", "cores": cores, "one_thread_value": c1_one,
+                                    "sample": "BASELINE configs[0]: net 224x224 bs1 conf 0.5 nms 0.6, median of 7 passes after 2 warm-ups"}}
+
+
+KIND_NAMES = {0: "other", 1: "conv", 2: "stem", 3: "dwconv", 4: "sppf", 5: "maxpool", 6: "cbam", 7: "eca", 8: "asff", 9: "layernorm",
+              10: "attention", 14: "transformer_fused"}
+
+
+def _entry(bound, work, ms, n, peak, unit, extra=None):
+    """One roofline line: achieved = algorithmic work / measured time."""
+    ach = work / (ms * 1e-3) / (1e12 if bound == "mfma" else 1e9) if ms > 0 else 0.0
+    e = {"bound": bound, "n_launches": n, "ms_per_forward": round(ms, 4), "achieved": round(ach, 1), "peak": peak, "unit": unit,
+         "frac": round(ach / peak, 4)}
+    if extra:
+        e.update(extra)
+    return e
+
+
+def _event_ms(fn, reps=20):
+    """Average milliseconds of fn() between two events on torch's current stream (the stream the library launches on)."""
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(reps):
-        once()
-    dt = time.perf_counter() - t0
-    return {"value": round(bs * reps / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": "%s %dx%d bs%d fp32 fwd+decode+NMS, %d passes after 1 warm-up (torch CPU oracle)" % (kind, size, size, bs, reps)}
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def kernel_rooflines(ms, infos, precision, outs, B, S, nc, conf, nms_thr, dev):
+    """Per-kernel roofline entries for everything that is not a conv launch (north_star: achieved HBM GB/s for the elementwise,
+    pooling, attention and NMS kernels; SURVEY 8(d) byte / pair definitions).  Plan ops come from the same HIP-event pass as the
+    conv roofline; decode / filter / NMS are timed here with event pairs around repeated launches on resident tensors."""
+    import math
+    import numpy as np
+    from ccnet_amd import ops
+    from ccnet_amd.utils import bbox
+    mfma_peak = BF16_MFMA_PEAK_TFLOPS if precision == "bf16" else FP32_MFMA_PEAK_TFLOPS
+    agg = {}
+    for m, (k, f, b) in zip(ms, infos):
+        if k in (0, 1):
+            continue
+        a = agg.setdefault(k, [0.0, 0.0, 0.0, 0])
+        a[0] += m; a[1] += f; a[2] += b; a[3] += 1
+    out = {}
+    for k, (m, f, b, n) in agg.items():
+        name = KIND_NAMES.get(k, str(k))
+        if k in (10, 14):   # attention core / fused Transformer: MFMA work
+            out[name] = _entry("mfma", f, m, n, mfma_peak, "TFLOP/s", {"flops": f})
+        else:
+            extra = {"bytes": b}
+            if k == 6:      # CBAM: unique bytes (1R + 1W of x) and the dependency-forced figure (3R + 1W), SURVEY 8(d)
+                ach2 = 2.0 * b / (m * 1e-3) / 1e9 if m > 0 else 0.0
+                extra["pass_forced_3r1w"] = {"bytes": 2.0 * b, "achieved": round(ach2, 1), "frac": round(ach2 / HBM_PEAK_GBS, 4)}
+            out[name] = _entry("hbm", b, m, n, HBM_PEAK_GBS, "GB/s", extra)
+    # ---- decode / filter / NMS on the tensors of the last step
+    dec = bbox.decode_outputs(outs, [S, S])
+    A = dec.shape[1]
+    t_dec = _event_ms(lambda: bbox.decode_outputs(outs, [S, S]))
+    out["decode"] = _entry("hbm", 2.0 * B * A * (5 + nc) * 4, t_dec, 1, HBM_PEAK_GBS, "GB/s", {"bytes": 2.0 * B * A * (5 + nc) * 4})
+    cand = torch.empty(B, A, 7, dtype=torch.float32, device=dev)
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    t_fil = _event_ms(lambda: ops.filter_candidates(dec, nc, conf, cand, counts))
+    cnt = counts.cpu().numpy()
+    ncand = int(cnt.sum())
+    fbytes = B * A * (5 + nc) * 4.0 + 28.0 * ncand
+    out["filter"] = _entry("hbm", fbytes, t_fil, 1, HBM_PEAK_GBS, "GB/s", {"bytes": fbytes, "candidates": ncand})
+    nmax = max(int(cnt.max()), 1)
+    hw = torch.full((B, 2), S, dtype=torch.int32, device=dev)
+    t_nms = _event_ms(lambda: bbox._nms(cand, counts, nmax, nms_thr, hw))
+    cls = cand[..., 6].cpu().numpy()
+    pairs = 0.0
+    for b_ in range(B):
+        c_ = np.bincount(cls[b_, :cnt[b_]].astype(np.int64), minlength=nc).astype(np.float64)
+        pairs += float((c_ * (c_ - 1) / 2).sum())
+    out["nms"] = {"bound": "pairs", "n_launches": 1, "ms_per_forward": round(t_nms, 4), "candidates_per_image": round(ncand / B, 1),
+                  "same_class_iou_pairs": pairs, "iou_pairs_per_s": round(pairs / (t_nms * 1e-3), 1) if t_nms > 0 else 0.0,
+                  "note": "host workspace allocation included; latency-bound at this candidate count"}
+    # ---- SURVEY 8(d) NMS-only microbench: 10 000 boxes per image x 16 images, log-normal sizes, 6 classes, nms 0.6
+    rng = np.random.RandomState(0)
+    nb, n = 16, 10000
+    cnd = np.zeros((nb, n, 7), np.float32)
+    c = rng.uniform(0, 1, (nb, n, 2)); wh = np.exp(rng.normal(math.log(0.05), 0.5, (nb, n, 2)))
+    cnd[..., 0:2] = c - wh / 2; cnd[..., 2:4] = c + wh / 2
+    cnd[..., 4] = rng.uniform(0, 1, (nb, n)); cnd[..., 5] = 1.0; cnd[..., 6] = rng.randint(0, 6, (nb, n))
+    ct = torch.from_numpy(cnd).to(dev)
+    cts = torch.full((nb,), n, dtype=torch.int32, device=dev)
+    hw2 = torch.ones(nb, 2, dtype=torch.int32, device=dev)
+    t_mb = _event_ms(lambda: bbox._nms(ct, cts, n, 0.6, hw2), reps=5)
+    pairs_mb = 0.0
+    for b_ in range(nb):
+        c_ = np.bincount(cnd[b_, :, 6].astype(np.int64), minlength=6).astype(np.float64)
+        pairs_mb += float((c_ * (c_ - 1) / 2).sum())
+    out["nms_microbench"] = {"workload": "16 images x 10000 candidates, 6 classes, nms 0.6 (SURVEY 8d)", "ms": round(t_mb, 4),
+                             "same_class_iou_pairs": pairs_mb, "iou_pairs_per_s": round(pairs_mb / (t_mb * 1e-3), 1),
+                             "workspace_bytes": ops.nms_workspace_bytes(nb, n)}
+    return out
 
 
 def main():
@@ -98,24 +217,22 @@ def main():
     torch.cuda.set_device(dev)
 
     from ccnet_amd import synth
-    from ccnet_amd.parallel import all_gather_detections
+    from ccnet_amd.parallel import sharded_post_process
     from ccnet_amd.utils import bbox
 
     B, S = args.batch, args.size
     net = build_model(args.kind, args.precision).to(dev).set_precision(args.precision)
-    net.alias_outputs = True
-    # every rank owns its own slice of the global synthetic batch (image i depends only on its global index)
-    x = torch.stack([synth.synth_images(1, S, S, seed=1000 + rank * B + i)[0] for i in range(min(B, 8))], 0)
-    x = x.repeat((B + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
+    # every rank owns its own slice of the global synthetic batch: B DISTINCT images (image i depends only on its global index)
+    x = torch.cat([synth.synth_images(1, S, S, seed=1000 + rank * B + i) for i in range(B)], 0).contiguous().to(dev)
     info = [[i, S, S] for i in range(B)]
 
     def step():
         outs = net(x)
         dec = bbox.decode_outputs(outs, [S, S])
-        dets = bbox.post_process(dec, 6, [S, S], info, args.conf, args.nms)
         if world > 1:
-            dets = all_gather_detections(dets, device=cdev, max_local=B)
-        return dets
+            # local filter + NMS, then ONE all_gather of the device result buffer (RCCL with the nccl backend) and one D2H copy
+            return sharded_post_process(dec, 6, [S, S], info, args.conf, args.nms)
+        return bbox.post_process(dec, 6, [S, S], info, args.conf, args.nms)
 
     for _ in range(args.warmup):
         dets = step()
@@ -175,6 +292,7 @@ def main():
         with open(tf[-1]) as f:
             tj = json.load(f)
         roofline["traffic"] = round(tj["hot"]["hbm_bytes_per_launch"])
+        roofline["traffic_source"] = "committed profile profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command), not measured in this run" % os.path.basename(tf[-1])
         roofline["traffic_note"] = "%s: HBM-side bytes per MFMA-bound launch (%s); algorithmic bytes per launch %d" % (
             os.path.basename(tf[-1]), tj["correction"], round(tj["hot"]["algorithmic_bytes_per_launch"]))
         roofline["hbm_bound_launches"]["traffic"] = round(tj["thin"]["hbm_bytes_per_launch"])
@@ -213,6 +331,8 @@ def main():
                       "global_batch": world * B, "parallelism": "batch-sharded replicas x%d" % world,
                       "detections_last_step": int(sum(0 if d is None else d.shape[0] for d in dets))},
            "roofline": roofline}
+    if rank == 0:
+        out["kernels"] = kernel_rooflines(ms, infos, args.precision, net(x), B, S, 6, args.conf, args.nms, dev)
     if rank == 0 and world == 1:
         # the step in front of the path, reported beside the headline and not part of `value`: B NEU-DET-sized
         # 8-bit images resident in HBM -> the (B,3,S,S) fp32 batch (Pillow-exact bicubic + normalisation + CHW)

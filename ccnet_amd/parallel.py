@@ -76,3 +76,79 @@ def all_gather_detections(local, group=None, device=None, max_local=None):
             c = int(counts[i])
             out.append(None if c < 0 else rows[i, :c].copy())
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Device-side exchange: filter + NMS on the local shard, ONE all_gather of the device result buffer (rows, keep counts and
+# candidate counts as int32 bit patterns) BEFORE anything is copied to the host, then one device->host copy of the gathered
+# buffer.  With the nccl backend (= RCCL over xGMI) the collective runs on the process group's own stream behind the NMS
+# kernels, so no host round trip sits between the local NMS and the exchange (off the forward's critical path).
+_rows_guess = {}
+
+
+def sharded_post_process(prediction, num_classes, input_shape, image_info, conf_thres=0.5, nms_thres=0.4, group=None,
+                         total_images=None):
+    """post_process (utils/bbox.py:82-159) of this rank's shard + the detections all_gather.  prediction: (B_local, A, 5+nc)
+    CUDA tensor of the local images, image_info: their [name, iw, ih] rows.  Returns the list for the WHOLE batch in rank
+    order on every rank (same row contents as ccnet_amd.utils.bbox.post_process on the unsharded batch for the
+    shard-invariant nets).  total_images: size of the whole batch when the shards are uneven (shard_range); default: every
+    rank holds B_local images.  Without an initialised process group this is plain post_process."""
+    from . import ops
+    from .utils import bbox
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bbox.post_process(prediction, num_classes, input_shape, image_info, conf_thres, nms_thres)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B, A = int(prediction.shape[0]), int(prediction.shape[1])
+    if total_images is None:
+        locals_ = [B] * world
+    else:
+        locals_ = [hi - lo for lo, hi in (shard_range(total_images, r, world) for r in range(world))]
+        if locals_[rank] != B:
+            raise ValueError("sharded_post_process: rank %d holds %d images, shard_range says %d" % (rank, B, locals_[rank]))
+    bmax = max(max(locals_), 1)
+    dev = prediction.device
+    on_device = dist.get_backend(group) == "nccl"
+    pred = prediction.float().contiguous()
+    hw = bbox._image_hw(tuple((int(image_info[i][2]), int(image_info[i][1])) for i in range(B)), dev) if B else None
+    key = (tuple(locals_), A, str(dev))
+    nmax = min(_rows_guess.get(key, ROWS_GUESS), max(A, 1))
+    with torch.cuda.device(dev):
+        cand = torch.empty(max(B, 1), A, 7, dtype=torch.float32, device=dev)
+        counts0 = torch.zeros(bmax, dtype=torch.int32, device=dev)
+        if B and A:
+            ops.filter_candidates(pred, num_classes, conf_thres, cand, counts0[:B])
+        while True:
+            # rows (bmax, nmax, 7) | keep counts (bmax) | candidate counts (bmax): padding images carry zeros
+            n_rows = bmax * nmax * 7
+            both = torch.zeros(n_rows + 2 * bmax, dtype=torch.float32, device=dev)
+            both[n_rows + bmax:].view(torch.int32).copy_(counts0)
+            if B and A:
+                ws = torch.empty(ops.nms_workspace_bytes(B, nmax) + 256, dtype=torch.uint8, device=dev)
+                ws = ws[(-ws.data_ptr()) % 256:]
+                keep_idx = torch.empty(B, nmax, dtype=torch.int32, device=dev)
+                ops.nms(cand, counts0[:B], nmax, nms_thres, hw, both[:B * nmax * 7].view(B, nmax, 7), keep_idx,
+                        both[n_rows:n_rows + B].view(torch.int32), ws)
+            if on_device:
+                gathered = torch.empty(world * both.numel(), dtype=torch.float32, device=dev)
+                dist.all_gather_into_tensor(gathered, both, group=group)  # RCCL, ordered behind the NMS kernels
+                host = gathered.cpu().numpy().reshape(world, -1)
+            else:  # gloo (CPU tests, one-GPU rehearsal): the same buffer travels through the host
+                mine = both.cpu()
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine, group=group)
+                host = np.stack([p_.numpy() for p_ in parts])
+            cmax = int(host[:, n_rows + bmax:].view(np.int32).max())
+            # every rank sees every count, so all ranks size the next call alike and take the same branch below
+            _rows_guess[key] = min(max(A, 1), max(64, -(-(cmax + cmax // 4) // 64) * 64))
+            if len(_rows_guess) > 64:
+                _rows_guess.clear()
+            if cmax <= nmax:
+                break
+            nmax = min(cmax, A)
+    out = []
+    for r in range(world):
+        rows = host[r, :n_rows].reshape(bmax, nmax, 7)
+        nk = host[r, n_rows:n_rows + bmax].view(np.int32)
+        for i in range(locals_[r]):
+            out.append(rows[i, :nk[i]].copy() if A else None)
+    return out
