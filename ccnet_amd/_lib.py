@@ -59,6 +59,9 @@ def lib():
         L.ccnet_nms_workspace_bytes.argtypes = [i32, i32]
         L.ccnet_nms_workspace_bytes.restype = sz
         L.ccnet_nms.argtypes = [vp, vp, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp]
+        L.ccnet_nms_noalloc.argtypes = [vp, vp, i32, i32, i32, f64, vp, vp, vp, vp, vp]
+        L.ccnet_nms_noalloc_max_bytes.restype = sz
+        L.ccnet_nms_noalloc_init.argtypes = []
         ll = C.c_longlong
         L.ccnet_resample_ksize.argtypes = [i32, i32]
         L.ccnet_resample_coeffs.argtypes = [i32, i32, vp, vp, i32]

@@ -8,6 +8,7 @@
 //              -> 64x64 IoU bitmask tiles (one wave per tile, one 64-bit word per lane)
 //              -> sequential sweep, 64 boxes at a time resolved in registers -> gather + rescale (utils/bbox.py:145-158)
 #include <math.h>
+#include <mutex>
 #include "common.h"
 
 namespace {
@@ -548,16 +549,17 @@ extern "C" size_t ccnet_nms_workspace_bytes(int B, int nmax) {
     return nms_ws(B, nmax).total;
 }
 
-extern "C" int ccnet_nms(const float* cand_dev, const int32_t* counts_dev, int B, int A, int nmax, double nms_thres, const int32_t* image_hw_dev,
-                         float* det_dev, int32_t* keep_idx_dev, int32_t* nkeep_dev, void* workspace_dev, ccnet_stream stream) {
-    CC_REQUIRE(cand_dev && counts_dev && image_hw_dev && det_dev && keep_idx_dev && nkeep_dev && workspace_dev, "nms: null pointer");
-    CC_REQUIRE(B > 0 && B <= 65535 && A > 0 && nmax > 0 && nmax <= A, "nms: bad sizes (B=%d A=%d nmax=%d)", B, A, nmax);
-    CC_REQUIRE(((uintptr_t)workspace_dev % 256) == 0, "nms: workspace must be 256-byte aligned");
+// Shared by ccnet_nms (caller's workspace) and ccnet_nms_noalloc (the library's static scratch): arguments are validated,
+// then the kernels are submitted with `base` as their workspace.
+static int nms_submit(const char* who, const float* cand_dev, const int32_t* counts_dev, int B, int A, int nmax, double nms_thres,
+                      const int32_t* image_hw_dev, float* det_dev, int32_t* keep_idx_dev, int32_t* nkeep_dev, unsigned char* base, ccnet_stream stream) {
+    CC_REQUIRE(cand_dev && counts_dev && image_hw_dev && det_dev && keep_idx_dev && nkeep_dev && base, "%s: null pointer", who);
+    CC_REQUIRE(B > 0 && B <= 65535 && A > 0 && nmax > 0 && nmax <= A, "%s: bad sizes (B=%d A=%d nmax=%d)", who, B, A, nmax);
+    CC_REQUIRE(((uintptr_t)base % 256) == 0, "%s: workspace must be 256-byte aligned", who);
     const NmsWs ws = nms_ws(B, nmax);
-    CC_REQUIRE(ws.W <= 65535, "nms: nmax too large for one launch (%d)", nmax);
-    CC_REQUIRE((size_t)ws.W * 8 <= 64 * 1024, "nms: nmax too large (%d)", nmax);
+    CC_REQUIRE(ws.W <= 65535, "%s: nmax too large for one launch (%d)", who, nmax);
+    CC_REQUIRE((size_t)ws.W * 8 <= 64 * 1024, "%s: nmax too large (%d)", who, nmax);
     const int np = ws.W * 64;
-    unsigned char* base = (unsigned char*)workspace_dev;
     float4* boxes = (float4*)(base + ws.boxes);
     float4* sboxes = boxes + (size_t)B * np;
     float* scores = (float*)(base + ws.scores);
@@ -585,4 +587,61 @@ extern "C" int ccnet_nms(const float* cand_dev, const int32_t* counts_dev, int B
             return CCNET_OK;
         },
         stream, CCNET_OP_NMS, 0.0, 0.0);
+}
+
+extern "C" int ccnet_nms(const float* cand_dev, const int32_t* counts_dev, int B, int A, int nmax, double nms_thres, const int32_t* image_hw_dev,
+                         float* det_dev, int32_t* keep_idx_dev, int32_t* nkeep_dev, void* workspace_dev, ccnet_stream stream) {
+    return nms_submit("nms", cand_dev, counts_dev, B, A, nmax, nms_thres, image_hw_dev, det_dev, keep_idx_dev, nkeep_dev, (unsigned char*)workspace_dev,
+                      stream);
+}
+
+// ---- the entry point that allocates nothing (include/ccnet_hip.h: ccnet_nms_noalloc) ---------------------------------------
+// The NMS workspace (offset boxes, sorted boxes, scores, order, pair bitmask) lives in a file-scope device array instead of
+// caller memory.  Each GPU the library runs on holds its own copy at its own address for the life of the process; the array's
+// NAME is only a host-side stand-in, so the address is resolved once per device with hipGetSymbolAddress and only that pointer
+// is ever handed to a kernel.  Nothing in the array has to start at zero: every word a kernel reads was written earlier in the
+// same call (mask tiles, order and box slots are all produced for the rows < counts[b] that the later kernels read).
+namespace {
+constexpr size_t NMS_SCRATCH_BYTES = (size_t)32 << 20;
+constexpr int NMS_SCRATCH_MAX_DEV = 64;
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[NMS_SCRATCH_BYTES];
+namespace {
+void* g_scratch_ptr[NMS_SCRATCH_MAX_DEV] = {nullptr};
+std::mutex g_scratch_mu;
+// address of THIS device's copy of `scratch` (resolved on first use on the device, with that device current)
+int scratch_for_current_device(unsigned char** out) {
+    int dev = -1;
+    CC_HIP(hipGetDevice(&dev));
+    CC_REQUIRE(dev >= 0 && dev < NMS_SCRATCH_MAX_DEV, "nms_noalloc: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* ptr = nullptr;
+        CC_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+        if (ptr == nullptr) return ccnet_set_error(CCNET_EHIP, "nms_noalloc: hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = (unsigned char*)g_scratch_ptr[dev];
+    return CCNET_OK;
+}
+}  // namespace
+
+extern "C" size_t ccnet_nms_noalloc_max_bytes(void) { return NMS_SCRATCH_BYTES; }
+
+extern "C" int ccnet_nms_noalloc_init(void) {
+    unsigned char* ptr = nullptr;
+    return scratch_for_current_device(&ptr);
+}
+
+extern "C" int ccnet_nms_noalloc(const float* cand_dev, const int32_t* counts_dev, int B, int A, int nmax, double nms_thres,
+                                 const int32_t* image_hw_dev, float* det_dev, int32_t* keep_idx_dev, int32_t* nkeep_dev, ccnet_stream stream) {
+    CC_REQUIRE(B > 0 && B <= 65535 && A > 0 && nmax > 0 && nmax <= A, "nms_noalloc: bad sizes (B=%d A=%d nmax=%d)", B, A, nmax);
+    const size_t need = nms_ws(B, nmax).total;
+    CC_REQUIRE(need <= NMS_SCRATCH_BYTES,
+               "nms_noalloc: B=%d x nmax=%d needs %zu bytes of workspace, the static scratch holds %zu; use ccnet_nms with a caller workspace", B,
+               nmax, need, (size_t)NMS_SCRATCH_BYTES);
+    unsigned char* ptr = nullptr;
+    const int rc = scratch_for_current_device(&ptr);
+    if (rc != CCNET_OK) return rc;
+    return nms_submit("nms_noalloc", cand_dev, counts_dev, B, A, nmax, nms_thres, image_hw_dev, det_dev, keep_idx_dev, nkeep_dev, ptr, stream);
 }

@@ -160,6 +160,21 @@ int ccnet_nms(const float* cand_dev, const int32_t* counts_dev, int B, int A, in
               const int32_t* image_hw_dev, float* det_dev, int32_t* keep_idx_dev, int32_t* nkeep_dev, void* workspace_dev,
               ccnet_stream stream);
 
+/* ccnet_nms_noalloc: ccnet_nms without a caller workspace.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot allocate device memory at the call site -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  The workspace (offset boxes, sorted boxes, scores, order, pair bitmask) is a file-scope device array
+ * of ccnet_nms_noalloc_max_bytes() = 32 MiB inside the library; each GPU the library runs on holds its own copy until the
+ * process ends.  Same arguments, results and kernels as ccnet_nms; a (B, nmax) whose ccnet_nms_workspace_bytes exceeds the
+ * maximum is rejected with CCNET_EINVAL (use ccnet_nms then).  The call allocates nothing (no hipMalloc / hipFree / allocating
+ * library routine); the array's per-device address is resolved on the first call on a device, or ahead of time by
+ * ccnet_nms_noalloc_init() with that device current (do that before a graph capture).  Every call on one GPU shares that
+ * GPU's array: calls that overlap in time on one GPU (two streams, two threads) race -- serialise them or use ccnet_nms. */
+size_t ccnet_nms_noalloc_max_bytes(void);
+int ccnet_nms_noalloc_init(void);
+int ccnet_nms_noalloc(const float* cand_dev, const int32_t* counts_dev, int B, int A, int nmax, double nms_thres,
+                      const int32_t* image_hw_dev, float* det_dev, int32_t* keep_idx_dev, int32_t* nkeep_dev,
+                      ccnet_stream stream);
+
 /* ---- image preparation in front of the path ----------------------------------------------
  * Replaces tools/eval.py:134-140 (`image.resize((W, H), Image.BICUBIC)`, float32, /255, mean/std, HWC->CHW) and the
  * letterbox of utils/datasets.py:123-134 (+ :73-77).  The resize is Pillow's ImagingResample for 8-bit images (third
