@@ -59,8 +59,8 @@ struct PatchQ {
             constexpr int ky = tap / 3, kx = tap - ky * 3; \
             const int bpar = (cpar ^ tap) & 1; \
             int after = 0; \
-            if (tap < 8) b_tile(bpar ^ 1, b_koff(cur_cc, tap + 1)); \
-            else if (next_chunk) b_tile(bpar ^ 1, b_koff(ncc, 0)); \
+            if (tap < 8) b_tile(bpar ^ 1, b_koff(kb_cur, tap + 1)); \
+            else if (next_chunk) b_tile(bpar ^ 1, b_koff(kb_next, 0)); \
             if (tap < PIECES && next_chunk) { \
                 patch_piece(tap, cpar ^ 1, pf_s1, pf_soff); \
                 after = 1; \
@@ -105,7 +105,7 @@ _Pragma("unroll") \
             asm volatile("" ::: "memory"); \
     }
 
-template <typename T, typename OutT, int BN, int MC, int ACT>
+template <typename T, typename OutT, int BN, int MC, int ACT, bool S2D>
 __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
     constexpr int MR = 16 / MC, TH = 8 * MR, TW = MC, PW = MC + 2;
     static_assert((TH + 2) * PW == PPIX && (PW % 2) == 0, "patch geometry");
@@ -160,42 +160,52 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
             const int lc = (lane & 7) ^ ((px >> 1) & 7);
             int ch = lc * EPC;  // first channel of the lane's chunk within the BK-channel window
             int dx = 0;
-            if (p.s2d && p.Creal < BK) { dx = ch >= p.Creal ? 1 : 0; ch -= dx * p.Creal; }  // Creal == BK/2 there
+            if (S2D && p.Creal < BK) { dx = ch >= p.Creal ? 1 : 0; ch -= dx * p.Creal; }  // Creal == BK/2 there
             pr_c[i] = (unsigned)ch * ES;
             const int vy = ty * TH - 1 + py, vx = tx * TW - 1 + px;
             const bool ok = tv && r < PPIX && (unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv;
-            const int sy = p.s2d ? 2 * vy : vy, sx = p.s2d ? 2 * vx + dx : vx;
+            const int sy = S2D ? 2 * vy : vy, sx = S2D ? 2 * vx + dx : vx;
             pix[i] = ok ? ((int)b * p.Hin + sy) * p.Win + sx : -1;
         }
     };
-    // chunk cc of the prefetch tile -> (segment, uniform byte offset)
+    // chunk cc of the prefetch tile -> (segment, uniform byte offset); every quantity here is wave-uniform and is kept in
+    // scalar registers explicitly (readfirstlane): left to the compiler, the resource / offset choice of the patch DMA became
+    // a waterfall loop and the pixel stride a scalar load followed by a full lgkmcnt(0) wait, once per piece
+    const unsigned ldcB0 = p.seg[0].ldcB, ldcB1 = p.seg[1].ldcB;
     auto chunk_src = [&](int cc, bool& s1, unsigned& soff) {
-        if (p.s2d) {
+        if (S2D) {
             const int v0 = cc * BK;
             const int q = v0 / p.Creal, c0 = v0 - q * p.Creal;  // q = 2*dy + dx of the first channel
             s1 = false;
-            soff = (unsigned)((q >> 1) * p.Win + (p.Creal < BK ? 0 : (q & 1))) * p.seg[0].ldcB + (unsigned)c0 * ES;
+            soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((q >> 1) * p.Win + (p.Creal < BK ? 0 : (q & 1))) * ldcB0 + (unsigned)c0 * ES));
         } else {
             const int c = cc * BK;
-            s1 = c >= p.C0;
-            soff = (unsigned)(c - (s1 ? p.C0 : 0)) * ES;
+            s1 = __builtin_amdgcn_readfirstlane((int)(c >= p.C0)) != 0;
+            soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(c - (s1 ? p.C0 : 0)) * ES));
         }
     };
     auto patch_piece = [&](int i, int buf, bool s1, unsigned soff) {
-        const unsigned ldcB = s1 ? p.seg[1].ldcB : p.seg[0].ldcB;
+        const unsigned ldcB = s1 ? ldcB1 : ldcB0;
         const unsigned v = pix[i] >= 0 ? (unsigned)pix[i] * ldcB + pr_c[i] : OOB;
-        const __amdgpu_buffer_rsrc_t r = s1 ? rsrcA1 : rsrcA0;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(patch0 + buf * PATCH_BYTES + (wave + 4 * i) * 1024), 16, (int)v, (int)soff, 0, 0);
+        if (s1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA1, (lds_void*)(patch0 + buf * PATCH_BYTES + (wave + 4 * i) * 1024), 16, (int)v, (int)soff, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA0, (lds_void*)(patch0 + buf * PATCH_BYTES + (wave + 4 * i) * 1024), 16, (int)v, (int)soff, 0, 0);
     };
-    // weights of K step (cc, tap): byte offset of its 128-B slice in a packed row
-    auto b_koff = [&](int cc, int tap) -> int {
-        if (p.s2d) {
+    // weights of K step (cc, tap): byte offset of its 128-B slice in a packed row = kbase(cc) + tapmul(tap) * tstride, where
+    // only kbase depends on the chunk (computed once per chunk, scalar) and tapmul is a compile-time constant of the step
+    const int kstride = __builtin_amdgcn_readfirstlane((S2D ? p.Creal : p.Ctot) * ES);
+    auto kbase = [&](int cc) -> int {
+        if (S2D) {
             const int v0 = cc * BK;
             const int q = v0 / p.Creal, c0 = v0 - q * p.Creal;
-            const int u = tap / 3, v = tap - u * 3;
-            return ((((2 * u + (q >> 1)) * 6 + 2 * v + (q & 1)) * p.Creal) + c0) * ES;
+            return __builtin_amdgcn_readfirstlane(((((q >> 1) * 6 + (q & 1)) * p.Creal) + c0) * ES);
         }
-        return (tap * p.Ctot + cc * BK) * ES;
+        return __builtin_amdgcn_readfirstlane(cc * BK * ES);
+    };
+    auto b_koff = [&](int kb, int tap) -> int {
+        const int u = tap / 3, v = tap - u * 3;
+        return kb + (S2D ? 12 * u + 2 * v : tap) * kstride;
     };
     auto b_tile = [&](int buf, int koff) {
 #pragma unroll
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
     chunk_src(pf_cc, pf_s1, pf_soff);
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) patch_piece(i, 0, pf_s1, pf_soff);
-    b_tile(0, b_koff(0, 0));
+    b_tile(0, b_koff(kbase(0), 0));
     // advance the prefetch cursor to chunk 1
     auto pf_advance = [&]() {
         if (++pf_cc == p.nchunks) {
@@ -339,8 +349,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
         const bool next_chunk = ci + 1 < total_chunks;
         const int cpar = (int)(ci & 1);
         const unsigned char* pt = patch0 + cpar * PATCH_BYTES;
-        // chunk after the current one (for the weights of its first tap)
-        const int ncc = cur_cc + 1 == p.nchunks ? 0 : cur_cc + 1;
+        // weight offsets of this chunk and of the one after it (for the weights of its first tap)
+        const int kb_cur = kbase(cur_cc);
+        const int kb_next = kbase(cur_cc + 1 == p.nchunks ? 0 : cur_cc + 1);
         PATCH_STEP(0) PATCH_STEP(1) PATCH_STEP(2) PATCH_STEP(3) PATCH_STEP(4) PATCH_STEP(5) PATCH_STEP(6) PATCH_STEP(7) PATCH_STEP(8)
         if (next_chunk) pf_advance();
         if (++cur_cc == p.nchunks) {
@@ -353,9 +364,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
     if (pending) epilogue(pend_tile);
 }
 
-template <typename T, typename OutT, int BN, int MC, int ACT>
-int launch_patch_act(const PatchQ& p, hipStream_t st) {
-    auto kernel = conv_patch_kernel<T, OutT, BN, MC, ACT>;
+template <typename T, typename OutT, int BN, int MC, int ACT, bool S2D>
+int launch_patch_s2d(const PatchQ& p, hipStream_t st) {
+    auto kernel = conv_patch_kernel<T, OutT, BN, MC, ACT, S2D>;
     constexpr int LDS = 2 * PATCH_BYTES + 2 * BN * BKB;
     static int cached[16] = {0};
     int dev = 0;
@@ -374,6 +385,11 @@ int launch_patch_act(const PatchQ& p, hipStream_t st) {
     hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(256), LDS, st, p);
     CC_LAUNCH_CHECK();
     return CCNET_OK;
+}
+
+template <typename T, typename OutT, int BN, int MC, int ACT>
+int launch_patch_act(const PatchQ& p, hipStream_t st) {
+    return p.s2d ? launch_patch_s2d<T, OutT, BN, MC, ACT, true>(p, st) : launch_patch_s2d<T, OutT, BN, MC, ACT, false>(p, st);
 }
 
 template <typename T, typename OutT, int BN, int MC>
