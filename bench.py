@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--conf", type=float, default=0.5)
     ap.add_argument("--nms", type=float, default=0.6)
+    ap.add_argument("--cand-per-image", type=int, default=0,
+                    help="place --conf so that about this many anchors per image survive the filter (BASELINE configs[4]: ~10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-op-kind time table to stderr")
     return ap.parse_args()
@@ -225,6 +227,15 @@ def main():
     # every rank owns its own slice of the global synthetic batch: B DISTINCT images (image i depends only on its global index)
     x = torch.cat([synth.synth_images(1, S, S, seed=1000 + rank * B + i) for i in range(B)], 0).contiguous().to(dev)
     info = [[i, S, S] for i in range(B)]
+
+    if args.cand_per_image > 0:
+        # the confidence threshold is placed where ~N of the anchors per image survive (the random-weight
+        # net has no meaningful operating point of its own); done once, before anything is timed
+        dec0 = bbox.decode_outputs(net(x), [S, S])
+        score = (dec0[..., 4] * dec0[..., 5:].max(-1).values).flatten()
+        k = min(max(score.numel() - args.cand_per_image * B, 1), score.numel())
+        args.conf = float(score.kthvalue(k).values)
+        del dec0, score
 
     def step():
         outs = net(x)
