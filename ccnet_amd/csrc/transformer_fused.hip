@@ -3,17 +3,29 @@
 // The reference builds nn.Transformer with batch_first=False and feeds it (B, HW, d): the sequence axis is the image
 // batch (S = B) and the H*W spatial positions are the "batch" (SURVEY fact 3).  Attention therefore only ever mixes the
 // S tokens that share a spatial position, and every other op (linear, LayerNorm, residual) is per token: the 6 encoder
-// + 6 decoder layers decompose into H*W INDEPENDENT problems of S <= 64 tokens x 256 channels.  One workgroup (8 waves)
-// owns one position, keeps its 64 x 256 activation stream, the encoder memory, the attention output and one head's
-// Q/K/V in LDS (156 KB of the CU's 160 KB) and runs all twelve layers without touching HBM for activations; what it
-// streams is the weights (22 MB bf16, L2/Infinity-Cache resident, read by every workgroup).
+// + 6 decoder layers decompose into H*W INDEPENDENT problems of S <= 64 tokens x 256 channels.
+//
+// One workgroup of FOUR waves owns one position and needs 80 KB of LDS, so TWO workgroups share a CU: 400 positions (a
+// 640x640 batch) are all resident at once on the 512 slots, and a workgroup's barrier / softmax / LayerNorm phases run
+// beside the other workgroup's GEMMs (the previous version held 156 KB per position: one workgroup per CU, two rounds of
+// positions, the matrix pipe idle whenever the one workgroup synchronised).  LDS per workgroup:
+//   X  [64][256] bf16, 32 KB : the activation stream; pre-LayerNorm sums and LayerNorm results are written IN PLACE
+//   A, B, C  [64][128] bf16, 16 KB each : Q_h / K_h / V_h of the head being processed; the head's attention output reuses A
+//                                        (out_proj is accumulated per head); A|B holds an FFN hidden chunk; B|C stages the
+//                                        encoder memory for the cross-attention K/V projections; C holds the LayerNorm table
+// The encoder memory itself lives in global memory -- in the rows of the OUTPUT tensor, which nothing else touches until
+// the final decoder.norm overwrites them.
 //
 // Weights are packed on the host into one stream PER WAVE, in the exact order that wave consumes them: fragment =
 // 16 output rows x 32 k as the 64-lane A operand of v_mfma_f32_16x16x32_bf16 (1 KB, lane l: row l&15, k (l>>4)*8..+7).
-// A wave keeps a ring of 16 fragments in registers and refills each slot as it is consumed (128 KB per CU in flight).
-// The weights are the MFMA "A" operand, so a lane ends up with 4 consecutive output channels of one token.
-// Rounding points (bf16) are those of the per-op path: projections, attention output, pre-LayerNorm sums, LayerNorm
-// outputs, the FFN hidden layer; all accumulation, softmax and LayerNorm statistics are fp32.
+// A wave keeps a ring of 16 fragments in registers and refills each slot as it is consumed.  The weights are the MFMA
+// "A" operand, so a lane ends up with 4 consecutive output channels of one token and every epilogue is register-only.
+//
+// Attention core without a probability tile: scores are computed TRANSPOSED (S^T = K Q^T, keys on the accumulator rows), so
+// a lane's 16 score registers are 16 keys of ONE query; after the softmax they ARE the B operand of O^T = V^T P^T under a
+// permuted key order that the V fragments (transposing LDS reads) follow.  Rounding points (bf16) are those of the per-op
+// path: projections, probabilities, attention output, pre-LayerNorm sums, LayerNorm outputs, the FFN hidden layer; all
+// accumulation, softmax and LayerNorm statistics are fp32.
 //
 // Fixed geometry: d_model 256, 2 heads of 128, FF 1024 (the s-width model), S <= 64.  Other shapes use the per-op path.
 #include "common.h"
@@ -25,23 +37,23 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 constexpr int E = 256, HD = 128, FF = 1024, SM = 64;
-constexpr int RING = 16;
-constexpr int NW = 8;                   // waves per workgroup
-constexpr int XB = SM * E * 2;           // 32768: a swizzled [64][256] bf16 GEMM operand
-constexpr int QLD = HD + 8;              // padded row of the per-head Q/K/V tiles (elements)
-constexpr int QB = SM * QLD * 2;         // 17408
-constexpr int ZLD = E + 8;               // padded row of the pre-LayerNorm tile (elements)
-constexpr int PLD = 72;
-constexpr int OFF_X = 0, OFF_MEM = XB, OFF_AO = 2 * XB, OFF_T = 3 * XB;  // T: Q|K|V of one head, or hidden chunk, or Z
-constexpr int T_BYTES = 3 * QB;          // 52224 >= 64*ZLD*2 = 33792 and >= XB
-constexpr int OFF_P = OFF_T + T_BYTES;
-constexpr int LDS_BYTES = OFF_P + 4 * 16 * PLD * 2;  // 159744
+#ifndef TF_RING
+#define TF_RING 8
+#endif
+constexpr int RING = TF_RING;
+constexpr int STREAM_PAD = 16;             // zero fragments behind each wave's stream (host layout, ops.py:pack_transformer)
+static_assert(RING <= STREAM_PAD, "the ring prefetches RING fragments past the end of the stream");
+constexpr int NW = 4;                    // waves per workgroup
+constexpr int XB = SM * E * 2;           // 32768: a swizzled [64][256] bf16 GEMM operand (512-byte rows)
+constexpr int HB = SM * HD * 2;          // 16384: a [64][128] bf16 tile (256-byte rows)
+constexpr int OFF_X = 0, OFF_A = XB, OFF_B = XB + HB, OFF_C = XB + 2 * HB;
+constexpr int LDS_BYTES = XB + 3 * HB;   // 81920: two workgroups fill a CU's 160 KB exactly
 
 struct TfP {
     const unsigned char* src;  // tokens: row (s*N + n), E bf16 each, row stride src_ld elements
     unsigned char* out;
     int src_ld, out_ld, S, N;
-    const unsigned char* wstream;  // [NW waves][frags_per_wave + RING][64 lanes][16 B]
+    const unsigned char* wstream;  // [NW waves][frags_per_wave + 16][64 lanes][16 B]
     long long frags_per_wave;
     const float* params;
     int n_enc, n_dec;
@@ -50,31 +62,11 @@ struct TfP {
 
 // byte offset of (row, 8-element chunk) in a swizzled [64][256] operand: conflict-free ds_read_b128 B-operand fragments
 __device__ __forceinline__ int xoff(int row, int chunk) { return row * 512 + (((chunk & 16) | ((chunk ^ row) & 15)) << 4); }
-
-// acc[mt][j] += W(16 rows of n-tile j) . src(tokens of m-tile mt), K = 256, consuming NTW*8 fragments of the wave's stream.
-// lx[k4] = this lane's byte offset of B-operand chunk (4*k4 + fq) in row fr of a swizzled operand (see xoff): the other
-// address terms are immediates.  `start` = ring slot of the first fragment; a compile-time constant after unrolling.
-template <int NTW>
-__device__ __forceinline__ void mm256(f32x4 (&acc)[4][NTW], const unsigned char* src, u32x4 (&ring)[RING], const unsigned char*& wp,
-                                      int loff, const int (&lx)[4], int start = 0) {
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt) {
-        u32x4 xb[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) xb[mt] = *(const u32x4*)(src + lx[kt & 3] + mt * 8192 + (kt >> 2) * 256);
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            const int slot = (start + kt * NTW + j) % RING;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[slot]), __builtin_bit_cast(bf16x8, xb[mt]), acc[mt][j], 0, 0, 0);
-            ring[slot] = *(const u32x4*)(wp + RING * 1024 + loff);  // refill with the fragment RING ahead (wp is wave uniform)
-#ifndef TF_NOADVANCE  // perf ablation: re-read the same fragments (cache hits) instead of streaming
-            wp += 1024;
-#endif
-        }
-    }
-}
+// the same for a [64][128] tile (16 chunks per row)
+__device__ __forceinline__ int qoff(int row, int chunk) { return row * 256 + (((chunk ^ row) & 15) << 4); }
+// V tile [key][128]: 32-byte column blocks XOR-ed with the row, so that the 4-row x 32-byte groups of ds_read_b64_tr_b16
+// (and the two such groups of a 32-lane half) fall on distinct banks
+__device__ __forceinline__ int voff(int row, int col) { return row * 256 + ((((col >> 4) ^ row) & 7) << 5) + (col & 15) * 2; }
 
 template <int NTW>
 __device__ __forceinline__ void zero(f32x4 (&acc)[4][NTW]) {
@@ -84,69 +76,75 @@ __device__ __forceinline__ void zero(f32x4 (&acc)[4][NTW]) {
         for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-#ifdef TF_STAMP  // diagnostic build: cycles per phase (0 GEMM, 1 epilogue, 2 barrier, 3 attention core, 4 LayerNorm)
-__device__ unsigned long long g_tf_stamps[8];
-#define TS(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_last; st_last = n_; } while (0)
-#define TPH(i) st_ph = (i)
-#define TSYNC() do { TS(st_ph); __syncthreads(); TS(2); } while (0)
-#else
-#define TS(i)
-#define TPH(i)
-#define TSYNC() __syncthreads()
-#endif
+// acc[mt][j] += W(16 rows of n-tile j) . src(tokens of m-tile mt) over KT k-tiles of 32, consuming NTW*KT fragments of the
+// wave's stream (k-tile major, n-tile minor).  src is a swizzled operand with ROWB-byte rows; lk[kt & 3] = this lane's byte
+// offset of chunk (4*(kt&3) + fq) in row fr, the other address terms are immediates.  Every call consumes a multiple of RING
+// fragments, so the ring slot of each fragment is a compile-time constant.
+template <int NTW, int KT, int ROWB>
+__device__ __forceinline__ void mm(f32x4 (&acc)[4][NTW], const unsigned char* src, u32x4 (&ring)[RING], const unsigned char*& wp, int loff,
+                                   const int (&lk)[4]) {
+    static_assert((NTW * KT) % RING == 0, "a GEMM call must consume whole ring turns");
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        u32x4 xb[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xb[mt] = *(const u32x4*)(src + lk[kt & 3] + mt * 16 * ROWB + (kt >> 2) * 256);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int slot = (kt * NTW + j) % RING;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[slot]), __builtin_bit_cast(bf16x8, xb[mt]), acc[mt][j], 0, 0, 0);
+            ring[slot] = *(const u32x4*)(wp + RING * 1024 + loff);  // refill with the fragment RING ahead (wp is wave uniform)
+            wp += 1024;
+        }
+        // bound how far the scheduler hoists the operand reads of later k-tiles
+        if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
-// all-reduce over the 16 lanes of a DPP row (the lanes that share fq): xor-1 and xor-2 inside quads, then the two mirror
-// steps -- four DPP-modified VALU instructions instead of four ds_bpermute round trips
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, dpp_f<0xB1>(v));   // quad_perm [1,0,3,2]
-    v = fmaxf(v, dpp_f<0x4E>(v));   // quad_perm [2,3,0,1]
-    v = fmaxf(v, dpp_f<0x141>(v));  // row_half_mirror
-    v = fmaxf(v, dpp_f<0x140>(v));  // row_mirror
-    return v;
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_f<0xB1>(v);
-    v += dpp_f<0x4E>(v);
-    v += dpp_f<0x141>(v);
-    v += dpp_f<0x140>(v);
+// An opaque copy of a lane-derived value.  The swizzled LDS addresses of the epilogues are invariant across the layer loops;
+// left alone, the compiler hoists dozens of them out of those loops and then spills them (hundreds of bytes of scratch per
+// lane).  Recomputing them per call from a laundered lane index costs a few VALU instructions beside thousands of MFMAs.
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
     return v;
 }
 
 __device__ __forceinline__ uint2 pack4(const float* v) { return make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
 
-// 8 waves (two per SIMD, so that one wave's LDS / VALU / barrier time hides under the other's MFMAs).  Wave w owns
-// output columns [32w, 32w+32) of every 256-wide GEMM and columns [16w, 16w+16) of each per-head Q/K/V projection.
+// workgroup barrier that waits for this wave's LDS traffic only: the weight ring's global loads stay in flight across it
+#define TSYNC() __syncthreads()
+
+// Four waves.  Wave w owns output columns [64w, 64w+64) of every 256-wide GEMM, columns [32w, 32w+32) of each per-head
+// Q/K/V projection, and query tile w (16 queries) of the attention core.
 __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP p) {
     extern __shared__ __align__(16) unsigned char sm[];
-    const int t = threadIdx.x, lane = t & 63;
+    const int t = threadIdx.x, lane = t & 63, lane0 = lane;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
+    const int fr = lane & 15, fq = lane >> 4, fr0 = fr, fq0 = fq;
     const int n = blockIdx.x;
     unsigned char* X = sm + OFF_X;
-    unsigned char* MEM = sm + OFF_MEM;
-    unsigned char* AO = sm + OFF_AO;
-    unsigned char* Tb = sm + OFF_T;
-    const int qt = wave & 3, half = wave >> 2;  // attention core: query tile and half of the head's columns
-    unsigned short* Pw = (unsigned short*)(sm + OFF_P) + qt * 16 * PLD;
-    int lx[4];
+    unsigned char* RA = sm + OFF_A;
+    unsigned char* RB = sm + OFF_B;
+    unsigned char* RC = sm + OFF_C;
+    int lx[4], lq[4];  // B-operand chunk offsets of this lane in a 512-byte-row / 256-byte-row operand
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) lx[k4] = fr * 512 + ((((k4 * 4) ^ fr ^ fq) & 15) << 4);
+    for (int k4 = 0; k4 < 4; ++k4) {
+        lx[k4] = fr * 512 + ((((k4 * 4) ^ fr ^ fq) & 15) << 4);
+        lq[k4] = fr * 256 + ((((k4 * 4 + fq) ^ fr) & 15) << 4);
+    }
 
     // ---- weight ring
-    const unsigned char* wp = p.wstream + (size_t)wave * (size_t)(p.frags_per_wave + RING) * 1024;  // wave uniform
+    const unsigned char* wp = p.wstream + (size_t)wave * (size_t)(p.frags_per_wave + STREAM_PAD) * 1024;  // wave uniform
     const int loff = lane * 16;
     u32x4 ring[RING];
 #pragma unroll
     for (int i = 0; i < RING; ++i) ring[i] = *(const u32x4*)(wp + i * 1024 + loff);
     const float* pp = p.params;
-#ifdef TF_STAMP
-    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
-    int st_ph = 1;
-#endif
+    // rows of p.out as a buffer resource (the encoder memory is read back through it; checked < 2 GiB on the host)
+    const __amdgpu_buffer_rsrc_t mem_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(((size_t)p.S * p.N - 1) * p.out_ld * 2 + E * 2), 0x00020000);
 
     // tokens of this position -> X (rows >= S are zero)
     auto load_src = [&]() __attribute__((always_inline)) {
@@ -158,19 +156,17 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
         }
     };
 
-    // LayerNorm of the 64 rows of Z (pre-LayerNorm sums, padded rows in T) or of X itself -> dst (swizzled operand) and
-    // optionally the global output.  Lane = row, wave = 32-channel slice: each lane sums its slice serially, the 8 slices
-    // of a row meet through a 4 KB LDS table (one barrier) -- no cross-lane shuffles (a 64-lane butterfly is 6 dependent
-    // ds_bpermute per reduction and made LayerNorm a quarter of the kernel).  Statistics in fp32, one pass (sum, sum of
-    // squares).
-    float2* lnpart = (float2*)(sm + OFF_P);  // [64 rows][8 slices]; the P tiles are idle outside the attention core
-    auto layernorm = [&](unsigned char* dst, const float* gb, bool from_x, bool to_global) __attribute__((always_inline)) {
-        TPH(4);
-        const int row = lane;
-        float v[32];
+    // LayerNorm of the 64 rows of X, in place (and optionally to the global output).  Lane = row, wave = 64-channel slice:
+    // each lane sums its slice serially and the four slices of a row meet through a 2 KB table in region C -- no cross-lane
+    // shuffles.  Statistics in fp32, one pass (sum, sum of squares).  A wave's slice is exactly the columns its own GEMM
+    // epilogue wrote, so nothing but the wave's own LDS traffic has to be waited for before phase 1.
+    float2* lnpart = (float2*)RC;  // [64 rows][4 slices]
+    auto layernorm = [&](const float* gb, bool to_lds, bool to_global) __attribute__((always_inline)) {
+        const int row = opaque(lane);
+        float v[64];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u32x4 raw = from_x ? *(const u32x4*)(X + xoff(row, 4 * wave + q)) : *(const u32x4*)(Tb + (row * ZLD + 32 * wave + 8 * q) * 2);
+        for (int q = 0; q < 8; ++q) {
+            const u32x4 raw = *(const u32x4*)(X + xoff(row, 8 * wave + q));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 v[8 * q + 2 * e] = bf16_bits_to_f32(raw[e] & 0xFFFFu);
@@ -179,243 +175,310 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
         }
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+        for (int e = 0; e < 64; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
         lnpart[row * NW + wave] = make_float2(s1, s2);
         TSYNC();
-        TPH(4);
-        float t1 = 0.0f, t2 = 0.0f;
-#pragma unroll
-        for (int w = 0; w < NW; w += 2) {
-            const float4 pr = *(const float4*)(&lnpart[row * NW + w]);
-            t1 += pr.x + pr.z;
-            t2 += pr.y + pr.w;
-        }
+        const float4 p01 = *(const float4*)(&lnpart[row * NW]);
+        const float4 p23 = *(const float4*)(&lnpart[row * NW + 2]);
+        const float t1 = (p01.x + p01.z) + (p23.x + p23.z);
+        const float t2 = (p01.y + p01.w) + (p23.y + p23.w);
         const float mean = t1 * (1.0f / E);
         const float var = fmaxf(t2 * (1.0f / E) - mean * mean, 0.0f);
         const float rs = rsqrtf(var + 1e-5f);
-        const float* g = gb + 32 * wave;       // wave-uniform: scalar loads
-        const float* bt = gb + E + 32 * wave;
+        const float* g = gb + 64 * wave;       // wave-uniform: scalar loads
+        const float* bt = gb + E + 64 * wave;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
             u32x4 pk;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = 8 * q + 2 * e;
                 pk[e] = pack_bf16x2((v[c] - mean) * rs * g[c] + bt[c], (v[c + 1] - mean) * rs * g[c + 1] + bt[c + 1]);
             }
-            *(u32x4*)(dst + xoff(row, 4 * wave + q)) = pk;
-            if (to_global && row < p.S) *(u32x4*)(p.out + ((size_t)((size_t)row * p.N + n) * p.out_ld + 32 * wave + 8 * q) * 2) = pk;
+            if (to_lds) *(u32x4*)(X + xoff(row, 8 * wave + q)) = pk;
+            if (to_global && row < p.S) *(u32x4*)(p.out + ((size_t)((size_t)row * p.N + n) * p.out_ld + 64 * wave + 8 * q) * 2) = pk;
         }
     };
+    auto add_ln = [&](bool to_lds, bool to_global) __attribute__((always_inline)) {
+        layernorm(pp, to_lds, to_global);
+        pp += 2 * E;
+        TSYNC();
+    };
 
-    // acc (+ bias + residual from X) -> Z
-    auto to_z = [&](f32x4 (&acc)[4][2], const float4 (&bias2)[2]) __attribute__((always_inline)) {
+    // acc (+ bias + residual from X) -> X in place (each element is read and written by the same lane)
+    auto to_z = [&](f32x4 (&acc)[4][4], const float4 (&bias4)[4]) __attribute__((always_inline)) {
+        const int fr = opaque(fr0), fq = opaque(fq0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n0 = wave * 32 + j * 16 + fq * 4;
-            const float4 bv = bias2[j];
+        for (int j = 0; j < 4; ++j) {
+            const int n0 = wave * 64 + j * 16 + fq * 4;
+            const float4 bv = bias4[j];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int row = mt * 16 + fr;
-                const uint2 rx = *(const uint2*)(X + xoff(row, n0 >> 3) + (n0 & 4) * 2);
+                unsigned char* px = X + xoff(row, n0 >> 3) + (n0 & 4) * 2;
+                const uint2 rx = *(const uint2*)px;
                 float v[4] = {acc[mt][j][0] + bv.x + bf16_bits_to_f32(rx.x & 0xFFFFu), acc[mt][j][1] + bv.y + bf16_bits_to_f32(rx.x >> 16),
                               acc[mt][j][2] + bv.z + bf16_bits_to_f32(rx.y & 0xFFFFu), acc[mt][j][3] + bv.w + bf16_bits_to_f32(rx.y >> 16)};
-                *(uint2*)(Tb + (row * ZLD + n0) * 2) = pack4(v);
+                *(uint2*)px = pack4(v);
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LayerNorm that follows reads this wave's own columns
     };
 
-    // multi-head attention block: queries from XQ, keys/values from XKV; result (+ bias + X residual) lands in Z
-    auto attention = [&](const unsigned char* XQ, const unsigned char* XKV) __attribute__((always_inline)) {
+    // multi-head attention block.  Queries from X; keys / values from X (self) or from the encoder memory kept in the rows of
+    // p.out (cross).  Result (+ bias + X residual) lands in X.
+    auto attention = [&](bool cross) __attribute__((always_inline)) {
+        const int fr = opaque(fr0), fq = opaque(fq0), lane = opaque(lane0);
         const float* in_bias = pp;         // q | k | v, 3E
         const float* out_bias = pp + 3 * E;
         pp += 4 * E;
-        unsigned short* Qs = (unsigned short*)Tb;
-        unsigned short* Ks = Qs + SM * QLD;
-        unsigned short* Vs = Ks + SM * QLD;
+        uint2 ao0[8];  // head 0's attention output of this lane (bf16), parked in registers while head 1 uses regions A, B, C
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            // projections of this head: wave w produces columns [16w, 16w+16) of Q_h, K_h and V_h
+            // encoder memory of this position -> B|C by LDS-DMA, requested now and awaited after the Q projection.  One wave
+            // instruction fills 1 KB = two 512-byte rows in lane order, so the operand's swizzle goes on the SOURCE address:
+            // the lane at physical chunk c' of row r fetches logical chunk (c' & 16) | ((c' ^ r) & 15).  Rows >= S lie beyond the
+            // tensor: the buffer resource's range check returns zeros for them.
+            if (cross) {
 #pragma unroll
-            for (int part = 0; part < 3; ++part) {
-                // biases are fetched BEFORE the GEMM: vector-memory results return in issue order, so a load issued after
-                // it would sit behind the 16 weight fragments the ring has in flight
-                const int c0 = wave * 16 + fq * 4;  // column inside the head
-                const float4 bv = *(const float4*)(in_bias + part * E + h * HD + c0);
-                f32x4 acc[4][1];
-                zero<1>(acc);
-                mm256<1>(acc, part == 0 ? XQ : XKV, ring, wp, loff, lx, ((h * 3 + part) * 8) % RING); TS(0); TPH(1);
-                unsigned short* dstT = part == 0 ? Qs : part == 1 ? Ks : Vs;
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    float v[4] = {acc[mt][0][0] + bv.x, acc[mt][0][1] + bv.y, acc[mt][0][2] + bv.z, acc[mt][0][3] + bv.w};
-                    *(uint2*)(dstT + (mt * 16 + fr) * QLD + c0) = pack4(v);
+                for (int k = 0; k < 8; ++k) {
+                    const int row = (wave * 8 + k) * 2 + (lane >> 5), pc = lane & 31;
+                    const int ch = (pc & 16) | ((pc ^ row) & 15);
+                    const unsigned voffset = row < p.S ? (unsigned)(((size_t)row * p.N + n) * p.out_ld + ch * 8) * 2u : 0x80000000u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(mem_rsrc, (__attribute__((address_space(3))) void*)(RB + (wave * 8 + k) * 1024), 16,
+                                                             (int)voffset, 0, 0, 0);
                 }
             }
+            // projections of this head: wave w produces columns [32w, 32w+32) of Q_h, K_h and V_h
+            const int c0 = wave * 32 + fq * 4;  // column inside the head (n-tile j adds 16)
+            // biases are fetched BEFORE the GEMM they follow: vector-memory results return in issue order, so a load issued
+            // after it would sit behind the 16 weight fragments the ring has in flight
+            auto ld_bias = [&](int part, float4 (&bv2)[2]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bv2[j] = *(const float4*)(in_bias + part * E + h * HD + c0 + j * 16);
+            };
+            auto put_qk = [&](unsigned char* dst, f32x4 (&acc)[4][2], const float4 (&bv2)[2]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 bv = bv2[j];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        float v[4] = {acc[mt][j][0] + bv.x, acc[mt][j][1] + bv.y, acc[mt][j][2] + bv.z, acc[mt][j][3] + bv.w};
+                        const int row = mt * 16 + fr, col = c0 + j * 16;
+                        *(uint2*)(dst + qoff(row, col >> 3) + (col & 4) * 2) = pack4(v);
+                    }
+                }
+            };
+            auto put_v = [&](f32x4 (&acc)[4][2], const float4 (&bv2)[2]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 bv = bv2[j];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        float v[4] = {acc[mt][j][0] + bv.x, acc[mt][j][1] + bv.y, acc[mt][j][2] + bv.z, acc[mt][j][3] + bv.w};
+                        *(uint2*)(RC + voff(mt * 16 + fr, c0 + j * 16)) = pack4(v);
+                    }
+                }
+            };
+            float4 bq[2], bk[2], bvv[2];
+            {
+                ld_bias(0, bq);
+                f32x4 acc[4][2];
+                zero<2>(acc);
+                mm<2, 8, 512>(acc, X, ring, wp, loff, lx);
+                put_qk(RA, acc, bq);
+            }
+            ld_bias(1, bk);
+            if (cross) {
+                // vector-memory operations retire in order: the Q projection issued 16 ring refills behind the 8 DMA pieces
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING) : "memory");
+                TSYNC();  // the staged memory is complete
+                f32x4 acck[4][2], accv[4][2];
+                zero<2>(acck);
+                zero<2>(accv);
+                mm<2, 8, 512>(acck, RB, ring, wp, loff, lx);
+                ld_bias(2, bvv);
+                mm<2, 8, 512>(accv, RB, ring, wp, loff, lx);
+                TSYNC();  // every wave has read the staged memory: K_h and V_h may overwrite it
+                put_qk(RB, acck, bk);
+                put_v(accv, bvv);
+            } else {
+                f32x4 acc[4][2];
+                zero<2>(acc);
+                mm<2, 8, 512>(acc, X, ring, wp, loff, lx);
+                put_qk(RB, acc, bk);
+                ld_bias(2, bvv);
+                zero<2>(acc);
+                mm<2, 8, 512>(acc, X, ring, wp, loff, lx);
+                put_v(acc, bvv);
+            }
             TSYNC();
-            TPH(3);
-            // scores of query tile qt against all 64 keys (both waves of a query tile compute them)
+            // transposed scores of query tile `wave`: s[i][r] = K[key i*16 + fq*4 + r] . Q[query wave*16 + fr]
             f32x4 s[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < HD / 32; ++ks) {
-                const u32x4 a = *(const u32x4*)(Qs + (qt * 16 + fr) * QLD + ks * 32 + fq * 8);
+                const u32x4 qf = *(const u32x4*)(RA + wave * 16 * 256 + lq[ks]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const u32x4 b = *(const u32x4*)(Ks + (i * 16 + fr) * QLD + ks * 32 + fq * 8);
-                    s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), s[i], 0, 0, 0);
+                    const u32x4 kf = *(const u32x4*)(RB + i * 16 * 256 + lq[ks]);
+                    s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf), s[i], 0, 0, 0);
                 }
             }
-            // softmax over keys (lane: rows fq*4+r, keys i*16+fr); keys >= S are masked
-            float inv[4];
+            // softmax over the keys of this lane's query: 16 registers, then the four lanes that share fr; keys >= S are masked
+            float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float mx = -INFINITY;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float v = (i * 16 + fr < p.S) ? s[i][r] * p.scale : -INFINITY;
+                for (int r = 0; r < 4; ++r) {
+                    const float v = (i * 16 + fq * 4 + r < p.S) ? s[i][r] * p.scale : -INFINITY;
                     s[i][r] = v;
                     mx = fmaxf(mx, v);
                 }
-                mx = row16_max(mx);
-                float sum = 0.0f;
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // the probabilities are rounded to bf16 where the per-op path rounds them (the P operand of PV); the
+                    // normalising sum is taken over the fp32 values, as there
                     const float pv = __expf(s[i][r] - mx);
                     s[i][r] = pv;
                     sum += pv;
                 }
-                sum = row16_sum(sum);
-                inv[r] = 1.0f / sum;
-            }
-            // P: C layout -> LDS tile of this query tile -> A fragments.  The two waves of a query tile write identical
-            // values to the same addresses and each reads back after its own writes, so no barrier is needed.
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+            TSYNC();  // every wave is done with Q_h and K_h
+            // O^T = V^T P^T.  k-step ks covers keys {(2ks + (j>>2))*16 + fq*4 + (j&3)}: exactly the lane's registers s[2ks][*], s[2ks+1][*]
+            f32x4 o[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int d = 0; d < 8; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // transposing reads: lane 4q+p of each 16-lane group addresses key row (base + q), d columns 4p..4p+3.  The row's
+            // low three bits do not depend on ks or on lo / hi, so the swizzled block of d-tile d is one per-lane constant
+            const int krow = fq * 4 + (fr >> 2);
+            const unsigned char* vbase = RC + krow * 256 + (fr & 3) * 8;
+            int vblk[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Pw[(fq * 4 + r) * PLD + i * 16 + fr] = (unsigned short)f32_to_bf16_bits(s[i][r]);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            f32x4 o[4];  // columns half*64 + i*16 + fr of the head
+            for (int d = 0; d < 8; ++d) vblk[d] = ((d ^ krow) & 7) << 5;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 pf;
+                pf[0] = pack_bf16x2(s[2 * ks][0], s[2 * ks][1]);
+                pf[1] = pack_bf16x2(s[2 * ks][2], s[2 * ks][3]);
+                pf[2] = pack_bf16x2(s[2 * ks + 1][0], s[2 * ks + 1][1]);
+                pf[3] = pack_bf16x2(s[2 * ks + 1][2], s[2 * ks + 1][3]);
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const u32x4 a = *(const u32x4*)(Pw + fr * PLD + k2 * 32 + fq * 8);
-                // transposed V block: lane 4q+p of each 16-lane group addresses key row (base + q), d columns 4p..4p+3
-                const unsigned short* vrow = Vs + (k2 * 32 + fq * 8 + (fr >> 2)) * QLD + half * 64 + (fr & 3) * 4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vrow + i * 16));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vrow + 4 * QLD + i * 16));
-                    const s16x8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), o[i], 0, 0, 0);
+                for (int d = 0; d < 8; ++d) {
+                    const unsigned char* pv = vbase + vblk[d] + (2 * ks) * 16 * 256;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pv);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pv + 16 * 256));
+                    const s16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf), o[d], 0, 0, 0);
+                    if ((d & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // O (rows fq*4+r of query tile qt) -> AO[:, h*HD + half*64 ..]
+            // O (query wave*16 + fr, channels h*128 + d*16 + fq*4 + r): head 0 waits in registers, then both heads go to A|B as
+            // the [64][256] B operand of out_proj
+            if (h == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = qt * 16 + fq * 4 + r;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int col = h * HD + half * 64 + i * 16 + fr;
-                    *(unsigned short*)(AO + xoff(row, col >> 3) + (col & 7) * 2) = (unsigned short)f32_to_bf16_bits(o[i][r] * inv[r]);
+                for (int d = 0; d < 8; ++d) {
+                    float v[4] = {o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv};
+                    ao0[d] = pack4(v);
                 }
+                TSYNC();  // every wave is done with V_0: the next head may overwrite regions A, B, C
+            } else {
+                TSYNC();  // every wave is done with V_1 (and, since the barrier after the scores, with Q_1 and K_1)
+                const int row = wave * 16 + fr;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    float v[4] = {o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv};
+                    const int c0h = d * 16 + fq * 4;
+                    *(uint2*)(RA + xoff(row, c0h >> 3) + (c0h & 4) * 2) = ao0[d];
+                    *(uint2*)(RA + xoff(row, (HD + c0h) >> 3) + (c0h & 4) * 2) = pack4(v);
+                }
+                TSYNC();  // the attention output is complete
             }
-            TSYNC();  // every wave is done with this head's K/V (and AO is complete after the second head)
         }
-        float4 ob[2];
+        f32x4 zacc[4][4];
+        zero<4>(zacc);
+        mm<4, 8, 512>(zacc, RA, ring, wp, loff, lx);
+        float4 ob[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ob[j] = *(const float4*)(out_bias + wave * 32 + j * 16 + fq * 4);
-        f32x4 acc[4][2];
-        zero<2>(acc);
-        mm256<2>(acc, AO, ring, wp, loff, lx); TS(0); TPH(1);
-        to_z(acc, ob);
-        TSYNC();
+        for (int j = 0; j < 4; ++j) ob[j] = *(const float4*)(out_bias + wave * 64 + j * 16 + fq * 4);
+        to_z(zacc, ob);
     };
 
     auto ffn = [&]() __attribute__((always_inline)) {
+        const int fr = opaque(fr0), fq = opaque(fq0);
         const float* b1 = pp;
         const float* b2 = pp + FF;
         pp += FF + E;
-        float4 b2v[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b2v[j] = *(const float4*)(b2 + wave * 32 + j * 16 + fq * 4);
-        f32x4 acc2[4][2];
-        zero<2>(acc2);
+        f32x4 acc2[4][4];
+        zero<4>(acc2);
         for (int c = 0; c < FF / 256; ++c) {
-            float4 hb[2];
+            float4 hb[4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) hb[j] = *(const float4*)(b1 + c * 256 + wave * 32 + j * 16 + fq * 4);
-            f32x4 acc1[4][2];
-            zero<2>(acc1);
-            mm256<2>(acc1, X, ring, wp, loff, lx); TS(0); TPH(1);
+            for (int j = 0; j < 4; ++j) hb[j] = *(const float4*)(b1 + c * 256 + wave * 64 + j * 16 + fq * 4);
+            f32x4 acc1[4][4];
+            zero<4>(acc1);
+            mm<4, 8, 512>(acc1, X, ring, wp, loff, lx);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n0 = wave * 32 + j * 16 + fq * 4;  // column inside the chunk
+            for (int j = 0; j < 4; ++j) {
+                const int n0 = wave * 64 + j * 16 + fq * 4;  // column inside the chunk
                 const float4 bv = hb[j];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     float v[4] = {fmaxf(acc1[mt][j][0] + bv.x, 0.f), fmaxf(acc1[mt][j][1] + bv.y, 0.f), fmaxf(acc1[mt][j][2] + bv.z, 0.f),
                                   fmaxf(acc1[mt][j][3] + bv.w, 0.f)};
-                    *(uint2*)(Tb + xoff(mt * 16 + fr, n0 >> 3) + (n0 & 4) * 2) = pack4(v);
+                    *(uint2*)(RA + xoff(mt * 16 + fr, n0 >> 3) + (n0 & 4) * 2) = pack4(v);
                 }
             }
             TSYNC();
-            mm256<2>(acc2, Tb, ring, wp, loff, lx); TS(0); TPH(1);
-            TSYNC();  // before the next chunk (or Z) overwrites the hidden tile
+            mm<4, 8, 512>(acc2, RA, ring, wp, loff, lx);
+            TSYNC();  // before the next chunk overwrites the hidden tile (or the LayerNorm table region C)
         }
+        float4 b2v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b2v[j] = *(const float4*)(b2 + wave * 64 + j * 16 + fq * 4);
         to_z(acc2, b2v);
-        TSYNC();
-    };
-    auto add_ln = [&](unsigned char* dst, bool from_x, bool to_global) __attribute__((always_inline)) {
-        layernorm(dst, pp, from_x, to_global);
-        pp += 2 * E;
-        TSYNC();
     };
 
     load_src();
     TSYNC();
     for (int l = 0; l < p.n_enc; ++l) {
-        attention(X, X);
-        add_ln(X, false, false);
+        attention(false);
+        add_ln(true, false);
         ffn();
-        add_ln(X, false, false);
+        add_ln(true, false);
     }
-    add_ln(MEM, true, false);  // encoder.norm
+    add_ln(false, true);  // encoder.norm: the memory goes to this position's rows of p.out (global), not to LDS
+    // the memory rows are read back by other waves of this workgroup: make the stores visible (they leave through L2) first
+    __threadfence_block();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the ring was drained by that wait: nothing is lost, its slots are simply complete
     load_src();  // nn.Transformer(src, src): the decoder starts from the same tokens
     TSYNC();
     for (int l = 0; l < p.n_dec; ++l) {
-        attention(X, X);
-        add_ln(X, false, false);
-        attention(X, MEM);
-        add_ln(X, false, false);
+        attention(false);
+        add_ln(true, false);
+        attention(true);
+        add_ln(true, false);
         ffn();
-        add_ln(X, false, false);
+        add_ln(true, false);
     }
-    add_ln(X, true, true);  // decoder.norm (dst X is scratch here; rows go to the output)
-#ifdef TF_STAMP
-    if (lane == 0 && wave == 1)
-        for (int i = 0; i < 5; ++i) atomicAdd(&g_tf_stamps[i], st_acc[i]);
-#endif
+    add_ln(false, true);  // decoder.norm: rows go to the output (overwriting the memory rows, which are no longer needed)
 }
 
 }  // namespace
 
-#ifdef TF_STAMP
-extern "C" int ccnet_debug_tf_stamps(unsigned long long* out8) {
-    CC_HIP(hipDeviceSynchronize());
-    CC_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tf_stamps), sizeof(unsigned long long) * 8));
-    unsigned long long z[8] = {0};
-    CC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tf_stamps), z, sizeof(z)));
-    return CCNET_OK;
-}
-#endif
-
 extern "C" int ccnet_transformer_fused_frags(int n_enc, int n_dec, long long* frags_per_wave, long long* param_floats) {
     CC_REQUIRE(n_enc >= 0 && n_dec >= 0 && frags_per_wave && param_floats, "transformer_fused_frags: bad arguments");
-    const long long attn = 2 * 3 * 8 + 16, ffn = 2 * (FF / 256) * 16;  // per wave, 8 waves
+    // per wave (4 waves): attention = 2 heads x (3 projections x 16 + out_proj slice 16), FFN = 4 chunks x (32 + 32)
+    const long long attn = 2 * (3 * 16 + 16), ffn = (FF / 256) * 64;
     *frags_per_wave = (long long)n_enc * (attn + ffn) + (long long)n_dec * (2 * attn + ffn);
     const long long pa = 4 * E, pl = 2 * E, pf = FF + E;
     *param_floats = (long long)n_enc * (pa + pl + pf + pl) + pl + (long long)n_dec * (2 * (pa + pl) + pf + pl) + pl;
@@ -431,6 +494,8 @@ extern "C" int ccnet_transformer_fused(const void* src, int src_ld, void* out, i
     CC_REQUIRE(S >= 1 && S <= SM && N >= 1, "transformer_fused: 1 <= S <= 64 tokens per position (got S=%d N=%d)", S, N);
     CC_REQUIRE(src_ld >= E && out_ld >= E && (src_ld % 8) == 0 && (out_ld % 8) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
                    ((uintptr_t)wstream % 16) == 0 && ((uintptr_t)params % 16) == 0, "transformer_fused: rows must be 16-byte aligned");
+    CC_REQUIRE((double)S * N * out_ld * 2.0 < 2147483648.0, "transformer_fused: output tensor of 2 GiB or more");
+    CC_REQUIRE(src != out, "transformer_fused: src and out must be different buffers (out also holds the encoder memory while the kernel runs)");
     long long need_f = 0, need_p = 0;
     ccnet_transformer_fused_frags(n_enc, n_dec, &need_f, &need_p);
     CC_REQUIRE(frags_per_wave == need_f, "transformer_fused: weight stream has %lld fragments per wave, expected %lld", frags_per_wave, need_f);

@@ -144,10 +144,10 @@ def _mfma_frags(w):
 def pack_transformer(sd, prefix, n_enc, n_dec, device):
     """Weight stream and parameter vector of ccnet_transformer_fused for the nn.Transformer under `prefix`
     (d_model 256, 2 heads, FF 1024).  The order below IS the kernel's program order (transformer_fused.hip), for each of
-    its 8 waves: per attention block, per head, Q/K/V projections (wave w owns 16 columns of each), then out_proj (wave w
-    owns 32 columns); per FFN, four 256-wide hidden chunks, linear1 chunk then the matching K slice of linear2.
-    Inside a GEMM call fragments run k-tile major, n-tile minor."""
-    E, FF, NW, RING = 256, 1024, 8, 16
+    its 4 waves: per attention block, per head, the Q/K/V projections (wave w owns 32 columns of each), then out_proj (wave w
+    owns 64 output columns); per FFN, four 256-wide hidden
+    chunks, linear1 chunk then the matching K slice of linear2.  Inside a GEMM call fragments run k-tile major, n-tile minor."""
+    E, FF, NW, RING = 256, 1024, 4, 16
     f64 = lambda t: t.detach().to(torch.float64).cpu()
 
     def attn(q):
@@ -158,12 +158,13 @@ def pack_transformer(sd, prefix, n_enc, n_dec, device):
             seq = []
             for h in range(2):
                 for part in range(3):
-                    nt = (part * E + h * 128 + w * 16) // 16
+                    nt = (part * E + h * 128 + w * 32) // 16
                     for kt in range(8):
-                        seq.append(fin[nt, kt])
+                        for j in range(2):
+                            seq.append(fin[nt + j, kt])
             for kt in range(8):
-                for j in range(2):
-                    seq.append(fout[w * 2 + j, kt])
+                for j in range(4):
+                    seq.append(fout[w * 4 + j, kt])
             per_wave.append(torch.stack(seq))
         return per_wave, [f64(sd[q + ".in_proj_bias"]), f64(sd[q + ".out_proj.bias"])]
 
@@ -175,11 +176,11 @@ def pack_transformer(sd, prefix, n_enc, n_dec, device):
             seq = []
             for c in range(FF // 256):
                 for kt in range(8):
-                    for j in range(2):
-                        seq.append(f1[c * 16 + w * 2 + j, kt])
+                    for j in range(4):
+                        seq.append(f1[c * 16 + w * 4 + j, kt])
                 for kt in range(8):
-                    for j in range(2):
-                        seq.append(f2[w * 2 + j, c * 8 + kt])
+                    for j in range(4):
+                        seq.append(f2[w * 4 + j, c * 8 + kt])
             per_wave.append(torch.stack(seq))
         return per_wave, [f64(sd[q + ".linear1.bias"]), f64(sd[q + ".linear2.bias"])]
 
