@@ -4,9 +4,9 @@
 //   decode   : sigmoid / exp / grid, one thread per anchor                       (utils/bbox.py:36-76)
 //   filter   : xyxy, class max, conf mask, stable compaction, one block per image (utils/bbox.py:98-130)
 //   nms      : coordinate-trick batched NMS                                       (utils/bbox.py:133-138 -> torchvision)
-//              prepare (max coordinate, offset boxes, scores) -> rank sort (stable, descending)
-//              -> 64x64 IoU bitmask tiles (one wave per tile, one 64-bit word per lane)
-//              -> sequential sweep, 64 boxes at a time resolved in registers -> gather + rescale (utils/bbox.py:145-158)
+//              bucket by class (max coordinate, offset boxes, scores, class groups) -> rank sort inside a group (stable,
+//              descending) -> 64x64 IoU bitmask tiles inside a group -> per-group sweep, 64 boxes at a time resolved in
+//              registers -> merge of the groups' kept lists by score + rescale (utils/bbox.py:145-158)
 #include <math.h>
 #include <mutex>
 #include "common.h"
@@ -131,22 +131,84 @@ __global__ __launch_bounds__(1024) void filter_kernel(const float* pred, int A, 
     if (t == 0) counts[b] = base_s;
 }
 
-// ---- NMS workspace (per image, nmax boxes; W = ceil(nmax/64) words)
+// ---- NMS workspace and per-image tables
+// torchvision's batched_nms adds cls * (max_coordinate + 1) to every box so that one global NMS never lets boxes of different
+// classes meet.  The tiled path below keeps that arithmetic (the offset boxes are what every IoU is computed from, so the bits
+// cannot change) and uses its consequence: the candidates of an image are bucketed by class, adjacent classes are merged into
+// one GROUP unless the offset boxes of everything before the boundary and everything after it are disjoint in x or in y (then
+// every cross pair has a zero intersection and can never suppress), and rank sort, pair bitmask and greedy sweep run per group.
+// The kept boxes of the groups are merged back into one list by (score descending, candidate index ascending), which is the
+// order the global algorithm emits.  A negative threshold (a zero overlap would suppress), a non-finite coordinate or a class
+// id outside 0..255 makes the image one group: that is the global algorithm itself.
+//
+// Pair bitmask storage: row i (sorted position) of a group that ends in 64-box chunk `we` holds the words of chunks
+// word(i)..we only, rows back to back (row_cum() is the closed form of the running total).  An image's rows are cut into
+// at most NMS_PANELS panels of <= cap words, a chunk never straddles two; mask and sweep are launched once per panel on the
+// same `cap` words, the sweep's state (removed bits, kept lists) persists in the workspace.  One class per image in the worst
+// case needs all four panels; six even classes need one.
+constexpr int NMS_MAXC = 256;    // class ids 0..255 are partitioned
+constexpr int NMS_TAB = 1024;    // ints of table per image
+constexpr int NMS_PANELS = 4;
+constexpr int NMS_GSLOTS = 32;   // sweep blocks per image (a block takes groups slot, slot + 32, ...)
+constexpr int T_G = 0, T_START = 8, T_CUM = 8 + 264, T_KEEP = 8 + 528;  // [T_START + g] first row of group g (.. G inclusive), [T_CUM + g] words before it, [T_KEEP + g] kept so far
 struct NmsWs {
-    size_t boxes, scores, order, mask, total;  // byte offsets
+    size_t boxes, sboxes, bkey, skey, kkey, rowgrp, table, removed, mask, total;  // byte offsets
     int W;
+    unsigned capq, cap;  // panel quantum and panel capacity in words per image
 };
 NmsWs nms_ws(int B, int nmax) {
     NmsWs w;
     w.W = (nmax + 63) / 64;
-    size_t np = (size_t)w.W * 64;
-    w.boxes = 0;                                         // float4 [B][np]  offset boxes, later sorted boxes
-    w.scores = w.boxes + (size_t)B * np * 16 * 2;        // two float4 planes: unsorted, sorted
-    w.order = w.scores + (size_t)B * np * 4;             // float [B][np]
-    w.mask = w.order + (size_t)B * np * 4;               // int [B][np]
-    w.mask = (w.mask + 255) & ~(size_t)255;
-    w.total = w.mask + (size_t)B * np * w.W * 8;         // u64 [B][np][W]
+    const size_t np = (size_t)w.W * 64, nb = (size_t)B * np;
+    size_t o = 0;
+    w.boxes = o;  o += nb * 16;   // float4 [B][np]  offset boxes in bucket order
+    w.sboxes = o; o += nb * 16;   // float4 [B][np]  offset boxes in sorted order (group-major, score descending inside a group)
+    w.bkey = o;   o += nb * 8;    // sort key (score, candidate index) of a bucket / sorted position, see nms_key()
+    w.skey = o;   o += nb * 8;
+    w.kkey = o;   o += nb * 8;    // [first row of group g + k] = key of the group's k-th kept box
+    w.rowgrp = o; o += nb * 2;    // group of a position (the same for bucket and sorted order)
+    o = (o + 255) & ~(size_t)255;
+    w.table = o;  o += (size_t)B * NMS_TAB * 4;
+    w.removed = o; o += (size_t)B * (w.W + NMS_MAXC) * 8;  // each group's span of removed words, private (offset by its index)
+    o = (o + 255) & ~(size_t)255;
+    // all rows of an image hold at most 32 W (W + 1) words (one group); a quarter of that per panel, plus one chunk of slack
+    // (small inputs: everything in one panel, up to 512 KB per image)
+    const unsigned all = 32u * (unsigned)w.W * (unsigned)(w.W + 1);
+    w.capq = all / 4u > (1u << 16) ? all / 4u : (all < (1u << 16) ? all : (1u << 16));
+    w.cap = w.capq + 64u * (unsigned)w.W;
+    w.mask = o;   o += (size_t)B * w.cap * 8;
+    w.total = o;
     return w;
+}
+
+// sum of (r >> 6) over r < m
+__device__ __forceinline__ unsigned tri64(unsigned m) {
+    const unsigned k = m >> 6;
+    return 32u * k * (k - 1u) + (m & 63u) * k;
+}
+// mask words of the image that precede sorted row i of group g (rows s..e-1, row r holds words (r >> 6)..((e-1) >> 6))
+__device__ __forceinline__ unsigned row_cum(const int* tab, int g, int i) {
+    const int s = tab[T_START + g], e = tab[T_START + g + 1];
+    const unsigned we = (unsigned)(e - 1) >> 6;
+    return (unsigned)tab[T_CUM + g] + (unsigned)(i - s) * (we + 1u) - (tri64((unsigned)i) - tri64((unsigned)s));
+}
+__device__ __forceinline__ int fkey(float f) {  // order-preserving float -> int (finite values)
+    const int v = __float_as_int(f);
+    return v >= 0 ? v : v ^ 0x7fffffff;
+}
+__device__ __forceinline__ float fkey_inv(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+// One unsigned key per candidate: box j comes before box i in the stable descending order (s_j > s_i, or s_j == s_i and
+// idx_j < idx_i) iff key_j > key_i.  High word: the score's bits made monotone (-0 counts as +0, like the float compare);
+// low word: ~idx.
+__device__ __forceinline__ unsigned long long nms_key(float score, int idx) {
+    const unsigned u = __float_as_uint(score == 0.0f ? 0.0f : score);
+    const unsigned m = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)m << 32) | (unsigned long long)(0xffffffffu - (unsigned)idx);
+}
+__device__ __forceinline__ int nms_key_idx(unsigned long long k) { return (int)(0xffffffffu - (unsigned)k); }
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
 }
 
 // word held by lane j (j wave-uniform) as a scalar: two v_readlane_b32 instead of two ds_bpermute round trips -- the greedy
@@ -183,155 +245,496 @@ __device__ __forceinline__ void write_det(const float* r, const int* image_hw, i
     d[4] = r[4]; d[5] = r[5]; d[6] = r[6];
 }
 
-// offset boxes = boxes + cls * (max_coordinate + 1)  (torchvision batched_nms coordinate trick); scores = obj * cls_conf
-__global__ __launch_bounds__(256) void nms_prepare_kernel(const float* cand, const int* counts, int A, int np, int nmax, float4* boxes, float* scores) {
-    __shared__ float red[4];
+// bucket the candidates of an image by class, form the groups, write the tables.  One block per image.
+//   offset boxes = boxes + cls * (max_coordinate + 1)  (torchvision batched_nms coordinate trick); scores = obj * cls_conf
+__global__ __launch_bounds__(1024) void nms_bucket_kernel(const float* __restrict__ cand, const int* __restrict__ counts, int A, int np, int nmax, int W,
+                                                          int split_ok, float4* boxes, unsigned long long* bkey, unsigned short* rowgrp, int* table,
+                                                          unsigned long long* removed) {
+    __shared__ int hist[NMS_MAXC], cursor[NMS_MAXC], gid[NMS_MAXC], cstart[NMS_MAXC + 1];
+    __shared__ int lox[NMS_MAXC], loy[NMS_MAXC], hix[NMS_MAXC], hiy[NMS_MAXC];
+    __shared__ float sfx[NMS_MAXC + 1], sfy[NMS_MAXC + 1];
+    __shared__ float red[16];
+    __shared__ int redw[16], redc[16];
     __shared__ float maxc_s;
-    const int b = blockIdx.x, t = threadIdx.x;
+    __shared__ int weird_s, ncls_s;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = min(counts[b], nmax);  // an image with more candidates than the caller sized for is cut, never overrun
+    int* tab = table + (size_t)b * NMS_TAB;
     const float* cb = cand + (size_t)b * A * 7;
+    float4* bx = boxes + (size_t)b * np;
+    unsigned short* rg = rowgrp + (size_t)b * np;
+    for (int c = t; c < NMS_MAXC; c += 1024) {
+        hist[c] = 0;
+        cursor[c] = 0;
+        lox[c] = loy[c] = 0x7fffffff;
+        hix[c] = hiy[c] = (int)0x80000000;
+        tab[T_KEEP + c] = 0;
+    }
+    for (int w = t; w < W + NMS_MAXC; w += 1024) removed[(size_t)b * (W + NMS_MAXC) + w] = 0ull;
+    __syncthreads();
+    // pass 1: largest coordinate, class histogram, can the image be partitioned at all
     float m = -INFINITY;
-    for (int i = t; i < n; i += 256) {
-        const float* r = cb + (size_t)i * 7;
-        m = fmaxf(m, fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])));
+    int weird = 0, cmax = 0;
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + t;
+        const bool act = i < n;
+        int ci = -1;
+        if (act) {
+            const float* r = cb + (size_t)i * 7;
+            const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3], cl = r[6];
+            m = fmaxf(m, fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)));
+            const float z = ((x1 - x1) + (y1 - y1)) + ((x2 - x2) + (y2 - y2));  // 0 iff every coordinate is finite
+            const int c = (cl >= 0.0f && cl < (float)NMS_MAXC) ? (int)cl : -1;
+            if (z == 0.0f && c >= 0 && (float)c == cl) {
+                ci = c;
+                cmax = max(cmax, c);
+            } else {
+                weird = 1;
+            }
+        }
+        unsigned long long todo = __ballot(ci >= 0);
+        while (todo) {  // one LDS atomic per (wave, class)
+            const int leader = __ffsll((long long)todo) - 1;
+            const int c = __builtin_amdgcn_readlane(ci, leader);
+            const unsigned long long same = __ballot(ci == c);
+            if (lane == leader) atomicAdd(&hist[c], __popcll(same));
+            todo &= ~same;
+        }
     }
     m = wave_max(m);
-    if ((t & 63) == 0) red[t >> 6] = m;
+    const float cmf = wave_max((float)cmax);
+    const unsigned long long anyw = __ballot(weird != 0);
+    if (lane == 0) {
+        red[wave] = m;
+        redc[wave] = (int)cmf;
+        redw[wave] = anyw != 0ull;
+    }
     __syncthreads();
-    if (t == 0) maxc_s = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (t == 0) {
+        float mm = red[0];
+        int cm = redc[0], wd = redw[0];
+        for (int q = 1; q < 16; ++q) {
+            mm = fmaxf(mm, red[q]);
+            cm = max(cm, redc[q]);
+            wd |= redw[q];
+        }
+        wd |= !split_ok;
+        maxc_s = mm;
+        weird_s = wd;
+        const int ncls = wd ? 1 : cm + 1;
+        ncls_s = ncls;
+        if (wd) hist[0] = n;
+        int acc = 0;
+        for (int c = 0; c < ncls; ++c) {
+            cstart[c] = acc;
+            acc += hist[c];
+        }
+        cstart[ncls] = acc;
+    }
     __syncthreads();
     const float step = maxc_s + 1.0f;
-    for (int i = t; i < n; i += 256) {
-        const float* r = cb + (size_t)i * 7;
-        const float off = r[6] * step;
-        boxes[(size_t)b * np + i] = make_float4(r[0] + off, r[1] + off, r[2] + off, r[3] + off);
-        scores[(size_t)b * np + i] = r[4] * r[5];
-    }
-}
-
-// stable descending rank: rank(i) = #{j : s_j > s_i or (s_j == s_i and j < i)}
-__global__ __launch_bounds__(256) void nms_rank_kernel(const int* counts, int np, int nmax, const float4* boxes, const float* scores, float4* sboxes,
-                                                       int* order) {
-    __shared__ float tile[256];
-    const int b = blockIdx.y, t = threadIdx.x;
-    const int n = min(counts[b], nmax);
-    if ((int)(blockIdx.x * 256) >= n) return;
-    const int i = blockIdx.x * 256 + t;
-    const float* sb = scores + (size_t)b * np;
-    const float si = i < n ? sb[i] : 0.0f;
-    int rank = 0;
-    for (int j0 = 0; j0 < n; j0 += 256) {
-        __syncthreads();
-        tile[t] = (j0 + t < n) ? sb[j0 + t] : -INFINITY;
-        __syncthreads();
-        const int jn = min(256, n - j0);
-        for (int j = 0; j < jn; ++j) {
-            const float sj = tile[j];
-            rank += (sj > si || (sj == si && (j0 + j) < i)) ? 1 : 0;
+    const int wd = weird_s, ncls = ncls_s;
+    // pass 2: placement by class (any order inside a class: the rank below breaks score ties by candidate index)
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + t;
+        const bool act = i < n;
+        float r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0;
+        if (act) {
+            const float* r = cb + (size_t)i * 7;
+            r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3]; r4 = r[4]; r5 = r[5]; r6 = r[6];
+        }
+        const int ci = act ? (wd ? 0 : (int)r6) : -1;
+        int pos = 0;
+        unsigned long long todo = __ballot(ci >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int c = __builtin_amdgcn_readlane(ci, leader);
+            const unsigned long long same = __ballot(ci == c);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&cursor[c], __popcll(same));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (ci == c) pos = cstart[c] + base + __popcll(same & ((1ull << lane) - 1ull));
+            todo &= ~same;
+        }
+        if (act) {
+            const float off = r6 * step;
+            bx[pos] = make_float4(r0 + off, r1 + off, r2 + off, r3 + off);
+            bkey[(size_t)b * np + pos] = nms_key(r4 * r5, i);
+            rg[pos] = (unsigned short)ci;
         }
     }
-    if (i < n) {
-        order[(size_t)b * np + rank] = i;
-        sboxes[(size_t)b * np + rank] = boxes[(size_t)b * np + i];
-    }
-}
-
-// one wave per 64x64 tile of the (sorted) pair matrix; lane = row, bit j = column
-__global__ __launch_bounds__(64) void nms_mask_kernel(const int* counts, int np, int W, int nmax, const float4* sboxes, double thr, unsigned long long* mask) {
-    __shared__ float4 cols[64];
-    const int b = blockIdx.z, rb = blockIdx.y, cbk = blockIdx.x;
-    const int n = min(counts[b], nmax);
-    if (cbk < rb || rb * 64 >= n || cbk * 64 >= n) return;
-    const int lane = threadIdx.x;
-    const float4* sb = sboxes + (size_t)b * np;
-    const int ci = cbk * 64 + lane;
-    cols[lane] = ci < n ? sb[ci] : make_float4(0, 0, 0, 0);
     __syncthreads();
-    const int i = rb * 64 + lane;
-    if (i >= n) return;
-    const float4 bi = sb[i];
-    const float ai = (bi.z - bi.x) * (bi.w - bi.y);
-    unsigned long long bits = 0;
-    const int jn = min(64, n - cbk * 64);
-    for (int j = 0; j < jn; ++j) {
-        const int gj = cbk * 64 + j;
-        if (gj <= i) continue;
-        if (suppresses(bi, ai, cols[j], thr)) bits |= 1ull << j;
-    }
-    mask[((size_t)b * np + i) * W + cbk] = bits;
-}
-
-// one block per image: sweep the sorted boxes 64 at a time
-__global__ __launch_bounds__(256) void nms_sweep_kernel(const int* counts, int np, int W, const unsigned long long* mask, const int* order, int nmax,
-                                                        int* keep_idx, int* nkeep) {
-    extern __shared__ unsigned long long removed[];  // [W]
-    __shared__ int kept_l[64];  // positions (0..63) of the boxes kept in the current chunk
-    __shared__ int kept_n;
-    const int b = blockIdx.x, t = threadIdx.x;
-    const int n = min(counts[b], nmax);
-    const int nw = (n + 63) / 64;
-    for (int w = t; w < nw; w += 256) removed[w] = 0ull;
-    __syncthreads();
-    const unsigned long long* mb = mask + (size_t)b * np * W;
-    const int* ob = order + (size_t)b * np;
-    int total = 0;  // meaningful in wave 0
-    for (int c = 0; c < nw; ++c) {
-        if (t < 64) {
-            const int i = c * 64 + t;
-            const unsigned long long diag = i < n ? mb[(size_t)i * W + c] : 0ull;
-            unsigned long long rem = removed[c];
-            unsigned long long kept = 0ull;
-            const int jn = min(64, n - c * 64);
-            for (int j = 0; j < jn; ++j) {
-                const unsigned long long dj = lane_word(diag, j);
-                if (!((rem >> j) & 1ull)) {
-                    kept |= 1ull << j;
-                    rem |= dj;
+    // pass 3: extent of each class's offset boxes (a wave whose 64 positions are one class reduces in registers)
+    if (!wd) {
+        for (int p0 = wave * 64; p0 < n; p0 += 1024) {
+            const int p = p0 + lane;
+            const bool act = p < n;
+            const float4 v = bx[act ? p : p0];
+            const int c = rg[act ? p : p0];
+            const int c0 = __builtin_amdgcn_readfirstlane(c);
+            if (__ballot(c != c0) == 0ull) {
+                const float ax = -wave_max(-v.x), ay = -wave_max(-v.y), zx = wave_max(v.z), zy = wave_max(v.w);
+                if (lane == 0) {
+                    atomicMin(&lox[c0], fkey(ax));
+                    atomicMin(&loy[c0], fkey(ay));
+                    atomicMax(&hix[c0], fkey(zx));
+                    atomicMax(&hiy[c0], fkey(zy));
                 }
+            } else {
+                atomicMin(&lox[c], fkey(v.x));
+                atomicMin(&loy[c], fkey(v.y));
+                atomicMax(&hix[c], fkey(v.z));
+                atomicMax(&hiy[c], fkey(v.w));
             }
-            if ((kept >> t) & 1ull) {
-                const int pos = total + __popcll(kept & ((1ull << t) - 1ull));
-                keep_idx[(size_t)b * nmax + pos] = ob[i];
-            }
-            total += __popcll(kept);
-            if ((kept >> t) & 1ull) kept_l[__popcll(kept & ((1ull << t) - 1ull))] = t;
-            if (t == 0) kept_n = __popcll(kept);
         }
-        __syncthreads();
-        // OR the mask rows of the kept boxes into the words still ahead.  The loads are what costs (L2 round trips), so
-        // they are spread over the whole block -- wave q takes every fourth kept row -- and issued 8 at a time; rows are
-        // picked with a clamped index (a repeated OR is harmless), so no load sits behind a branch.
-        const int nk = kept_n;
-        if (nk > 0) {
-            const int wave = t >> 6, lane = t & 63;
-            const int mine = (nk - wave + 3) / 4;  // kept rows wave, wave+4, ...
-            for (int w = c + 1 + lane; w < nw; w += 64) {
-                unsigned long long acc = 0ull;
-                for (int q = 0; q < mine; q += 8) {
-                    unsigned long long v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int idx = wave + 4 * min(q + u, mine - 1);
-                        v[u] = mb[(size_t)(c * 64 + kept_l[idx]) * W + w];
+    }
+    __syncthreads();
+    // groups: a boundary in front of class c iff everything before it and everything from it on are disjoint in x or in y
+    if (t == 0) {
+        int G = 0;
+        if (n > 0) {
+            if (wd) {
+                gid[0] = 0;
+                tab[T_START] = 0;
+                G = 1;
+            } else {
+                sfx[ncls] = sfy[ncls] = INFINITY;
+                for (int c = ncls - 1; c >= 0; --c) {
+                    sfx[c] = hist[c] ? fminf(sfx[c + 1], fkey_inv(lox[c])) : sfx[c + 1];
+                    sfy[c] = hist[c] ? fminf(sfy[c + 1], fkey_inv(loy[c])) : sfy[c + 1];
+                }
+                float phx = -INFINITY, phy = -INFINITY;
+                int g = -1;
+                for (int c = 0; c < ncls; ++c) {
+                    if (hist[c] == 0) {
+                        gid[c] = max(g, 0);
+                        continue;
                     }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) acc |= v[u];
+                    if (g < 0 || phx <= sfx[c] || phy <= sfy[c]) {
+                        ++g;
+                        tab[T_START + g] = cstart[c];
+                    }
+                    gid[c] = g;
+                    phx = fmaxf(phx, fkey_inv(hix[c]));
+                    phy = fmaxf(phy, fkey_inv(hiy[c]));
                 }
-                if (mine > 0 && acc) atomicOr(&removed[w], acc);
+                G = g + 1;
             }
         }
-        __syncthreads();
+        tab[T_G] = G;
+        tab[T_START + G] = n;
+        unsigned cum = 0;
+        for (int g = 0; g < G; ++g) {
+            const int s = tab[T_START + g], e = tab[T_START + g + 1];
+            const unsigned we = (unsigned)(e - 1) >> 6;
+            tab[T_CUM + g] = (int)cum;
+            cum += (unsigned)(e - s) * (we + 1u) - (tri64((unsigned)e) - tri64((unsigned)s));
+        }
+        tab[T_CUM + G] = (int)cum;
     }
-    if (t == 0) nkeep[b] = total;
+    __syncthreads();
+    for (int p = t; p < n; p += 1024) rg[p] = (unsigned short)gid[rg[p]];
 }
 
-// det row = cand[keep] rescaled like the numpy tail of post_process (bbox.py:145-158)
-__global__ __launch_bounds__(256) void nms_gather_kernel(const float* cand, int A, int nmax, const int* keep_idx, const int* nkeep, const int* image_hw,
-                                                         float* det) {
+// stable descending rank inside the group: rank(i) = #{j in the group : key_j > key_i}.  A wave owns 16 rows whose keys sit in
+// scalar registers and streams the group's keys 64 at a time, one per lane: a pair costs 1/64 of a 64-bit compare plus two
+// scalar instructions (count the ballot, add), instead of half a dozen vector instructions per pair and thread.
+constexpr int RANK_R = 16;
+__global__ __launch_bounds__(256) void nms_rank_kernel(const int* __restrict__ counts, int np, int nmax, const float4* __restrict__ boxes,
+                                                       const unsigned long long* __restrict__ bkey, const unsigned short* __restrict__ rowgrp,
+                                                       const int* __restrict__ table, float4* sboxes, unsigned long long* skey) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int n = min(counts[b], nmax);
+    const int p0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * RANK_R);
+    if (p0 >= n) return;
+    const int* tab = table + (size_t)b * NMS_TAB;
+    const size_t ib = (size_t)b * np;
+    const unsigned long long* kb = bkey + ib;
+    const int gf = rowgrp[ib + p0], gl = rowgrp[ib + min(p0 + RANK_R - 1, n - 1)];
+    const int lo = tab[T_START + gf], hi = tab[T_START + gl + 1];
+    unsigned long long ki[RANK_R];
+    int acc[RANK_R];
+#pragma unroll
+    for (int r = 0; r < RANK_R; ++r) {
+        ki[r] = uniform64(kb[min(p0 + r, n - 1)]);
+        acc[r] = 0;
+    }
+    if (gf == gl) {
+        for (int j0 = lo; j0 < hi; j0 += 256) {
+            unsigned long long kj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kj[u] = (j0 + u * 64 + lane < hi) ? kb[j0 + u * 64 + lane] : 0ull;  // 0 is above no key
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < RANK_R; ++r) acc[r] += __popcll(__ballot(kj[u] > ki[r]));
+        }
+    } else {  // the 16 rows straddle a group boundary: each row counts inside its own group only
+        int rs[RANK_R], re[RANK_R];
+#pragma unroll
+        for (int r = 0; r < RANK_R; ++r) {
+            const int g = rowgrp[ib + min(p0 + r, n - 1)];
+            rs[r] = tab[T_START + g];
+            re[r] = tab[T_START + g + 1];
+        }
+        for (int j0 = lo; j0 < hi; j0 += 64) {
+            const int j = j0 + lane;
+            const unsigned long long kj = j < hi ? kb[j] : 0ull;
+#pragma unroll
+            for (int r = 0; r < RANK_R; ++r) acc[r] += __popcll(__ballot(kj > ki[r] && j >= rs[r] && j < re[r]));
+        }
+    }
+    int mine = 0;
+#pragma unroll
+    for (int r = 0; r < RANK_R; ++r) mine = lane == r ? acc[r] : mine;
+    if (lane < RANK_R && p0 + lane < n) {
+        const int g = rowgrp[ib + p0 + lane];
+        const size_t q = ib + tab[T_START + g] + mine;
+        sboxes[q] = boxes[ib + p0 + lane];
+        skey[q] = kb[p0 + lane];
+    }
+}
+
+// pair bitmask of one panel.  Block = one 64-row chunk of the sorted list, lane = row; the four waves share the chunk's column
+// tiles (its own chunk .. the last chunk of the last group it touches).  A tile is done in two phases: a FILTER over all 64
+// columns -- four compares per pair: the boxes overlap in x and in y, which every pair with a non-zero intersection passes --
+// and the exact torchvision arithmetic (suppresses()) on the pairs that passed, each lane walking its own candidate bits.  With
+// a threshold >= 0 a pair with a zero (or NaN) intersection can never suppress, so the filter cannot change a bit.
+__global__ __launch_bounds__(256) void nms_mask_kernel(const int* __restrict__ counts, int np, int nmax, unsigned capq, unsigned cap, int panel,
+                                                       const float4* __restrict__ sboxes, const unsigned short* __restrict__ rowgrp,
+                                                       const int* __restrict__ table, double thr, int skip_zero, unsigned long long* mask) {
+    __shared__ float4 cols_s[4][64];
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int n = min(counts[b], nmax);
+    const int r0 = c * 64;
+    if (r0 >= n) return;
+    const int* tab = table + (size_t)b * NMS_TAB;
+    const float4* sb = sboxes + (size_t)b * np;
+    const unsigned short* rg = rowgrp + (size_t)b * np;
+    if ((int)(row_cum(tab, rg[r0], r0) / capq) != panel) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = r0 + lane, il = min(i, n - 1);
+    const int g = rg[il];
+    const int we = (tab[T_START + g + 1] - 1) >> 6;
+    const int wmax = (tab[T_START + rg[min(r0 + 63, n - 1)] + 1] - 1) >> 6;
+    unsigned long long* mrow = mask + (size_t)b * cap + (row_cum(tab, g, il) - (unsigned)panel * capq);
+    const float4 bi = sb[il];
+    const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+    float4* cols = cols_s[wave];
+    for (int ct = c + wave; ct <= wmax; ct += 4) {
+        const int jn = min(64, n - ct * 64);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        cols[lane] = sb[min(ct * 64 + lane, n - 1)];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        unsigned lo = 0u, hi = 0u;
+        if (skip_zero) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                const float4 bj = cols[j];
+                const bool hit = (bi.z > bj.x) & (bj.z > bi.x) & (bi.w > bj.y) & (bj.w > bi.y);
+                if (j < 32) lo |= hit ? (1u << j) : 0u; else hi |= hit ? (1u << (j - 32)) : 0u;
+            }
+        } else {
+            lo = hi = ~0u;
+        }
+        unsigned long long todo = ((unsigned long long)hi << 32) | lo;
+        if (jn < 64) todo &= (1ull << jn) - 1ull;
+        // the diagonal tile is kept SYMMETRIC (all j != i: the overlap test is symmetric bit for bit), so that the sweep has every
+        // row's predecessors without a transpose
+        if (ct == c) todo &= ~(1ull << lane);
+        unsigned long long bits = 0ull;
+        while (__ballot(todo != 0ull)) {
+            if (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                if (suppresses(bi, ai, cols[j], thr)) bits |= 1ull << j;
+            }
+        }
+        if (i < n && ct <= we) mrow[ct - c] = bits;
+    }
+}
+
+// greedy sweep of one panel: a block takes whole groups, 64 sorted boxes (one chunk) per step.  Wave 0 walks the dependent
+// chain: the chunk's diagonal words and the words of the NEXT chunk were fetched one step ahead, the 64 boxes are resolved in
+// scalar registers, and what the kept ones remove from the next chunk is OR-ed in at once.  The fifteen other waves run one
+// step behind: they OR the mask rows of the previous chunk's kept boxes into the removed words two or more chunks ahead (L2
+// round trips that the chain no longer waits for).
+constexpr int SWEEP_T = 1024, SWEEP_H = SWEEP_T / 64 - 1;
+__global__ __launch_bounds__(SWEEP_T) void nms_sweep_kernel(const int* __restrict__ counts, int np, int W, int nmax, unsigned capq, unsigned cap, int panel,
+                                                            const unsigned long long* __restrict__ mask, const unsigned short* __restrict__ rowgrp,
+                                                            const unsigned long long* __restrict__ skey, int* table, unsigned long long* removed_g,
+                                                            unsigned long long* kkey) {
+    extern __shared__ unsigned long long removed[];  // the group's span of words (<= W)
+    __shared__ int kept_l[2][64];  // lanes (0..63) of the boxes kept in the current / previous chunk
+    __shared__ int kept_n[2];
+    const int b = blockIdx.y, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int n = min(counts[b], nmax);
+    if (n <= 0) return;
+    int* tab = table + (size_t)b * NMS_TAB;
+    const int G = tab[T_G];
+    const unsigned long long* mb = mask + (size_t)b * cap;
+    const unsigned long long* sk = skey + (size_t)b * np;
+    const unsigned pbase = (unsigned)panel * capq;
+    for (int g = blockIdx.x; g < G; g += gridDim.x) {
+        const int s = tab[T_START + g], e = tab[T_START + g + 1];
+        const int c0 = s >> 6, we = (e - 1) >> 6, nwg = we - c0 + 1;
+        const unsigned gcum = (unsigned)tab[T_CUM + g];
+        // words before row r of this group / before the first row of chunk c (a row of an earlier group iff c == c0 and s is mid-chunk)
+        auto own_cum = [&](int r) -> unsigned { return gcum + (unsigned)(r - s) * (unsigned)(we + 1) - (tri64((unsigned)r) - tri64((unsigned)s)); };
+        auto chunk_panel = [&](int c) -> int {
+            const int r0 = c * 64;
+            return (int)((r0 >= s ? own_cum(r0) : row_cum(tab, rowgrp[(size_t)b * np + r0], r0)) / capq);
+        };
+        if (chunk_panel(c0) > panel || chunk_panel(we) < panel) continue;
+        unsigned long long* rem_g = removed_g + (size_t)b * (W + NMS_MAXC) + c0 + g;
+        __syncthreads();
+        for (int w = t; w < nwg; w += SWEEP_T) removed[w] = rem_g[w];
+        __syncthreads();
+        int total = tab[T_KEEP + g];  // meaningful in wave 0
+        // first and last chunk of the group inside this panel
+        int cf = c0;
+        while (chunk_panel(cf) < panel) ++cf;
+        int cl = cf;
+        while (cl < we && chunk_panel(cl + 1) == panel) ++cl;
+        // rows of chunk c that belong to the group: lanes a..z-1, `cnt` words each, the first at `rows`
+        auto lanes_a = [&](int c) { return max(s - c * 64, 0); };
+        auto lanes_z = [&](int c) { return min(e - c * 64, 64); };
+        auto rows_of = [&](int c) { return mb + (own_cum(c * 64 + lanes_a(c)) - pbase); };
+        unsigned long long d0 = 0ull, d1 = 0ull, k0 = 0ull;  // wave 0: diagonal word, next chunk's word and key of lane's row
+        if (wave == 0) {
+            const int a = lanes_a(cf), z = lanes_z(cf);
+            if (lane >= a && lane < z) {
+                const unsigned long long* r = rows_of(cf) + (size_t)(lane - a) * (unsigned)(we - cf + 1);
+                d0 = r[0];
+                d1 = cf < we ? r[1] : 0ull;
+                k0 = sk[cf * 64 + lane];
+            }
+        }
+        for (int c = cf; c <= cl + 1; ++c) {  // step cl + 1: only the helpers, for the last chunk's kept rows
+            const int cur = (c - cf) & 1;
+            if (wave == 0) {
+                if (c <= cl) {
+                    unsigned long long e0 = 0ull, e1 = 0ull, k1 = 0ull;
+                    if (c < cl) {  // fetch one step ahead
+                        const int a = lanes_a(c + 1), z = lanes_z(c + 1);
+                        if (lane >= a && lane < z) {
+                            const unsigned long long* r = rows_of(c + 1) + (size_t)(lane - a) * (unsigned)(we - c);
+                            e0 = r[0];
+                            e1 = c + 1 < we ? r[1] : 0ull;
+                            k1 = sk[(c + 1) * 64 + lane];
+                        }
+                    }
+                    const int a = lanes_a(c), z = lanes_z(c);
+                    // Greedy over the chunk without walking it box by box: d0 is the row of the symmetric overlap matrix, so
+                    // its bits below the lane are the boxes that would suppress this one if kept.  A box is removed as soon as
+                    // one of them is kept, kept as soon as none of them is kept or undecided; the lowest undecided box always
+                    // decides, and typical chunks settle in a few rounds instead of 64 dependent steps.
+                    const unsigned long long pred = d0 & ((1ull << lane) - 1ull);
+                    const unsigned long long span = (z >= 64 ? ~0ull : (1ull << z) - 1ull) & ~((1ull << a) - 1ull);
+                    unsigned long long und = span & ~uniform64(removed[c - c0]);
+                    unsigned long long kept = 0ull;
+                    while (und) {
+                        const bool u = (und >> lane) & 1ull;
+                        const unsigned long long out = __ballot(u && (pred & kept) != 0ull);
+                        const unsigned long long in = __ballot(u && (pred & (kept | und)) == 0ull);
+                        kept |= in;
+                        und &= ~(in | out);
+                    }
+                    const bool mine = (kept >> lane) & 1ull;
+                    if (mine && d1) atomicOr(&removed[c + 1 - c0], d1);
+                    const int before = __popcll(kept & ((1ull << lane) - 1ull));
+                    if (mine) {
+                        kkey[(size_t)b * np + s + total + before] = k0;
+                        kept_l[cur][before] = lane;
+                    }
+                    total += __popcll(kept);
+                    if (lane == 0) kept_n[cur] = __popcll(kept);
+                    d0 = e0; d1 = e1; k0 = k1;
+                }
+            } else if (c > cf) {
+                // helpers: rows kept in chunk c - 1, words of chunks c + 1 .. we.  Helper h takes kept rows h, h + 15, ...; all of
+                // a lane's loads are issued before the first OR (clamped index: a repeated OR is harmless)
+                const int pc = c - 1, prev = cur ^ 1;
+                const int nk = kept_n[prev];
+                const int h = wave - 1;
+                const int mine = (nk - h + SWEEP_H - 1) / SWEEP_H;
+                if (mine > 0 && pc + 2 <= we) {
+                    const int a = lanes_a(pc);
+                    const unsigned cnt = (unsigned)(we - pc + 1);
+                    const unsigned long long* rows = rows_of(pc);
+                    for (int w = pc + 2 + lane; w <= we; w += 64) {
+                        unsigned long long v[5];
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) v[u] = rows[(size_t)(kept_l[prev][h + SWEEP_H * min(u, mine - 1)] - a) * cnt + (w - pc)];
+                        const unsigned long long acc = (v[0] | v[1]) | (v[2] | v[3]) | v[4];
+                        if (acc) atomicOr(&removed[w - c0], acc);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        for (int w = t; w < nwg; w += SWEEP_T) rem_g[w] = removed[w];
+        if (t == 0) tab[T_KEEP + g] = total;
+    }
+}
+
+// merge the groups' kept lists into the global order (score descending, candidate index ascending: descending key) and write
+// the rows: det row = cand[keep] rescaled like the numpy tail of post_process (bbox.py:145-158).  The output slot of a kept box
+// is its place in its own list plus, for every other group, the number of that group's kept keys above it -- binary searches,
+// eight groups side by side so that their (dependent) loads overlap.
+__global__ __launch_bounds__(256) void nms_merge_kernel(const float* __restrict__ cand, const int* __restrict__ counts, int A, int np, int nmax,
+                                                        const unsigned short* __restrict__ rowgrp, const int* __restrict__ table,
+                                                        const unsigned long long* __restrict__ kkey, const int* __restrict__ image_hw, float* det,
+                                                        int* keep_idx, int* nkeep) {
     const int b = blockIdx.y;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= nkeep[b]) return;
-    write_det(cand + ((size_t)b * A + keep_idx[(size_t)b * nmax + k]) * 7, image_hw, b, det + ((size_t)b * nmax + k) * 7);
+    const int n = min(counts[b], nmax);
+    const int* tab = table + (size_t)b * NMS_TAB;
+    const int G = n > 0 ? tab[T_G] : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int tot = 0;
+        for (int g = 0; g < G; ++g) tot += tab[T_KEEP + g];
+        nkeep[b] = tot;
+    }
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const size_t ib = (size_t)b * np;
+    const int g = rowgrp[ib + q];
+    const int k = q - tab[T_START + g];
+    if (k >= tab[T_KEEP + g]) return;
+    const unsigned long long key = kkey[ib + q];
+    const int id = nms_key_idx(key);
+    int out = k;
+    for (int h0 = 0; h0 < G; h0 += 8) {
+        const unsigned long long* kl[8];
+        int lo[8], hi[8];
+        int open = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int h = h0 + u;
+            const bool on = h < G && h != g;
+            kl[u] = kkey + ib + tab[T_START + (h < G ? h : 0)];
+            lo[u] = 0;
+            hi[u] = on ? tab[T_KEEP + h] : 0;
+            open |= hi[u];
+        }
+        while (open) {  // kept boxes of group h in front of this one
+            open = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int mid = (lo[u] + hi[u]) >> 1;
+                const bool go = lo[u] < hi[u];
+                const unsigned long long km = go ? kl[u][mid] : 0ull;
+                if (go && km > key) lo[u] = mid + 1; else if (go) hi[u] = mid;
+                open |= hi[u] - lo[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) out += lo[u];
+    }
+    keep_idx[(size_t)b * nmax + out] = id;
+    write_det(cand + ((size_t)b * A + id) * 7, image_hw, b, det + ((size_t)b * nmax + out) * 7);
 }
 
 // ---- the whole NMS of one image in ONE block, for nmax <= SMALL_NMAX candidates per image: prepare, rank, mask, sweep and
@@ -560,11 +963,6 @@ static int nms_submit(const char* who, const float* cand_dev, const int32_t* cou
     CC_REQUIRE(ws.W <= 65535, "%s: nmax too large for one launch (%d)", who, nmax);
     CC_REQUIRE((size_t)ws.W * 8 <= 64 * 1024, "%s: nmax too large (%d)", who, nmax);
     const int np = ws.W * 64;
-    float4* boxes = (float4*)(base + ws.boxes);
-    float4* sboxes = boxes + (size_t)B * np;
-    float* scores = (float*)(base + ws.scores);
-    int* order = (int*)(base + ws.order);
-    unsigned long long* mask = (unsigned long long*)(base + ws.mask);
     const int W = ws.W;
     if (nmax <= SMALL_NMAX)
         return ccnet_submit(
@@ -575,14 +973,33 @@ static int nms_submit(const char* who, const float* cand_dev, const int32_t* cou
                 return CCNET_OK;
             },
             stream, CCNET_OP_NMS, 0.0, 0.0);
+    float4* boxes = (float4*)(base + ws.boxes);
+    float4* sboxes = (float4*)(base + ws.sboxes);
+    unsigned long long* bkey = (unsigned long long*)(base + ws.bkey);
+    unsigned long long* skey = (unsigned long long*)(base + ws.skey);
+    unsigned long long* kkey = (unsigned long long*)(base + ws.kkey);
+    unsigned short* rowgrp = (unsigned short*)(base + ws.rowgrp);
+    int* table = (int*)(base + ws.table);
+    unsigned long long* removed = (unsigned long long*)(base + ws.removed);
+    unsigned long long* mask = (unsigned long long*)(base + ws.mask);
+    const unsigned capq = ws.capq, cap = ws.cap;
+    const int split_ok = nms_thres >= 0.0 ? 1 : 0;  // below zero a ZERO overlap suppresses, across classes too: one group
+    const int panels = 32u * (unsigned)W * (unsigned)(W + 1) <= capq ? 1 : NMS_PANELS;  // small inputs always fit one panel
     return ccnet_submit(
         [=](hipStream_t st, const float*) -> int {
-            hipLaunchKernelGGL(nms_prepare_kernel, dim3(B), dim3(256), 0, st, cand_dev, counts_dev, A, np, nmax, boxes, scores);
-            hipLaunchKernelGGL(nms_rank_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, st, counts_dev, np, nmax, boxes, scores, sboxes, order);
-            hipLaunchKernelGGL(nms_mask_kernel, dim3(W, W, B), dim3(64), 0, st, counts_dev, np, W, nmax, sboxes, nms_thres, mask);
-            hipLaunchKernelGGL(nms_sweep_kernel, dim3(B), dim3(256), (size_t)W * 8, st, counts_dev, np, W, mask, order, nmax, keep_idx_dev, nkeep_dev);
-            hipLaunchKernelGGL(nms_gather_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, st, cand_dev, A, nmax, keep_idx_dev, nkeep_dev,
-                               image_hw_dev, det_dev);
+            const dim3 rows((nmax + 255) / 256, B);
+            hipLaunchKernelGGL(nms_bucket_kernel, dim3(B), dim3(1024), 0, st, cand_dev, counts_dev, A, np, nmax, W, split_ok, boxes, bkey, rowgrp, table,
+                               removed);
+            hipLaunchKernelGGL(nms_rank_kernel, dim3((nmax + 4 * RANK_R - 1) / (4 * RANK_R), B), dim3(256), 0, st, counts_dev, np, nmax, boxes, bkey,
+                               rowgrp, table, sboxes, skey);
+            for (int panel = 0; panel < panels; ++panel) {
+                hipLaunchKernelGGL(nms_mask_kernel, dim3(W, B), dim3(256), 0, st, counts_dev, np, nmax, capq, cap, panel, sboxes, rowgrp, table,
+                                   nms_thres, split_ok, mask);
+                hipLaunchKernelGGL(nms_sweep_kernel, dim3(NMS_GSLOTS, B), dim3(SWEEP_T), (size_t)W * 8, st, counts_dev, np, W, nmax, capq, cap, panel,
+                                   mask, rowgrp, skey, table, removed, kkey);
+            }
+            hipLaunchKernelGGL(nms_merge_kernel, rows, dim3(256), 0, st, cand_dev, counts_dev, A, np, nmax, rowgrp, table, kkey, image_hw_dev, det_dev,
+                               keep_idx_dev, nkeep_dev);
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
@@ -596,11 +1013,11 @@ extern "C" int ccnet_nms(const float* cand_dev, const int32_t* counts_dev, int B
 }
 
 // ---- the entry point that allocates nothing (include/ccnet_hip.h: ccnet_nms_noalloc) ---------------------------------------
-// The NMS workspace (offset boxes, sorted boxes, scores, order, pair bitmask) lives in a file-scope device array instead of
-// caller memory.  Each GPU the library runs on holds its own copy at its own address for the life of the process; the array's
-// NAME is only a host-side stand-in, so the address is resolved once per device with hipGetSymbolAddress and only that pointer
-// is ever handed to a kernel.  Nothing in the array has to start at zero: every word a kernel reads was written earlier in the
-// same call (mask tiles, order and box slots are all produced for the rows < counts[b] that the later kernels read).
+// The NMS workspace (offset boxes, sorted boxes, sort keys, group tables, pair bitmask panel) lives in a file-scope device array
+// instead of caller memory.  Each GPU the library runs on holds its own copy at its own address for the life of the process; the
+// array's NAME is only a host-side stand-in, so the address is resolved once per device with hipGetSymbolAddress and only that
+// pointer is ever handed to a kernel.  What has to start at zero -- the sweep's removed bits and kept counts -- is cleared by the
+// call's first kernel (nms_bucket_kernel); every other word a kernel reads was written earlier in the same call.
 namespace {
 constexpr size_t NMS_SCRATCH_BYTES = (size_t)32 << 20;
 constexpr int NMS_SCRATCH_MAX_DEV = 64;

@@ -149,7 +149,9 @@ int ccnet_decode(const float* const* head_dev, const int64_t* sb, const int64_t*
 int ccnet_filter(const float* pred_dev, int B, int A, int nc, float conf_thres, float* cand_dev, int32_t* counts_dev,
                  ccnet_stream stream);
 /* post_process part 2 (utils/bbox.py:133-158): torchvision.ops.boxes.batched_nms (0.9.0 coordinate trick; third party,
- * see DESIGN.md) + gather + rescale to image pixels.  nmax = rows provided per image: results are exact when
+ * see DESIGN.md) + gather + rescale to image pixels.  Above 256 rows per image the work is partitioned by class group
+ * (classes whose offset boxes cannot meet), which leaves every bit of the global algorithm's result unchanged.
+ * nmax = rows provided per image: results are exact when
  * nmax >= max(counts); an image with more candidates is processed on its first nmax only (never overrun), so a caller
  * may launch with an estimate and look at counts afterwards.  image_hw_dev: int32 [B][2] = (ih, iw).
  * det_dev: fp32 [B][nmax][7] rows [top,left,bottom,right,obj,cls_conf,cls_id] in descending score order;
@@ -162,7 +164,7 @@ int ccnet_nms(const float* cand_dev, const int32_t* counts_dev, int B, int A, in
 
 /* ccnet_nms_noalloc: ccnet_nms without a caller workspace.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
  * cannot allocate device memory at the call site -- code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc.  The workspace (offset boxes, sorted boxes, scores, order, pair bitmask) is a file-scope device array
+ * forbid hipMalloc.  The workspace (offset boxes, sorted boxes, sort keys, group tables, pair bitmask panel) is a file-scope device array
  * of ccnet_nms_noalloc_max_bytes() = 32 MiB inside the library; each GPU the library runs on holds its own copy until the
  * process ends.  Same arguments, results and kernels as ccnet_nms; a (B, nmax) whose ccnet_nms_workspace_bytes exceeds the
  * maximum is rejected with CCNET_EINVAL (use ccnet_nms then).  The call allocates nothing (no hipMalloc / hipFree / allocating

@@ -618,3 +618,56 @@ def test_nms_single_block_path_equals_tiled_path():
             assert np.array_equal(small[b][0], tiled[b][0]) and np.array_equal(small[b][1], tiled[b][1]), (n_per, b)
             ref = orc.batched_nms_reference(cand[b, :n, :4].numpy(), (cand[b, :n, 4] * cand[b, :n, 5]).numpy(), cand[b, :n, 6].numpy(), 0.5)
             assert np.array_equal(small[b][0], np.asarray(ref, dtype=small[b][0].dtype)), (n_per, b)
+
+
+def _nms_case(rng, n, ncls, lo, hi, size, cls_vals=None, ties=False):
+    """(n,7) candidates: centres uniform in [lo, hi], log-normal sizes around `size`, classes 0..ncls-1 (or drawn from cls_vals)."""
+    cand = np.zeros((n, 7), np.float32)
+    c = rng.uniform(lo, hi, (n, 2))
+    wh = np.exp(rng.normal(math.log(size), 0.6, (n, 2)))
+    cand[:, 0:2] = c - wh / 2
+    cand[:, 2:4] = c + wh / 2
+    cand[:, 4] = np.floor(rng.uniform(0, 1, n) * 16) / 16 + 0.03 if ties else rng.uniform(0, 1, n)
+    cand[:, 5] = rng.uniform(0.5, 1, n) if not ties else 1.0
+    cand[:, 6] = rng.randint(0, ncls, n) if cls_vals is None else np.asarray(cls_vals, np.float32)[rng.randint(0, len(cls_vals), n)]
+    return cand
+
+
+def test_nms_class_groups_bit_exact():
+    """The tiled NMS works per class GROUP (csrc/detect.hip): candidates bucketed by class, adjacent classes merged when their
+    offset boxes are not provably disjoint, rank / bitmask / sweep per group, kept lists merged by score.  It must stay bit-identical
+    to the global coordinate-trick algorithm of torchvision 0.9.0 (oracle.batched_nms_reference) in every regime:
+    separable classes; boxes hanging far outside the image so that the offset boxes of neighbouring classes OVERLAP and suppress
+    each other (the reference's quirk); one class only (all four mask panels); 80 classes (more groups than sweep blocks);
+    class ids the partition does not handle (>= 256, fractional); a negative threshold (a zero overlap suppresses); exact score
+    ties across classes; empty and one-box images beside large ones."""
+    from oracle import ccnet_oracle as orc
+    from ccnet_amd.utils import bbox
+    rng = np.random.RandomState(11)
+    cases = [
+        ("separable", [_nms_case(rng, 2500, 6, 0, 640, 40), _nms_case(rng, 1900, 6, 0, 640, 60, ties=True)], 0.6),
+        ("overhang", [_nms_case(rng, 2000, 4, -700, 700, 500), _nms_case(rng, 1500, 6, -100, 640, 200)], 0.5),
+        ("one_class", [_nms_case(rng, 3000, 1, 0, 640, 30), _nms_case(rng, 700, 1, 0, 64, 30)], 0.6),
+        ("80_classes", [_nms_case(rng, 4000, 80, 0, 640, 120), np.zeros((0, 7), np.float32), _nms_case(rng, 1, 80, 0, 640, 50)], 0.45),
+        ("odd_class_ids", [_nms_case(rng, 1200, 0, 0, 640, 80, cls_vals=[0, 3, 255, 256, 300]), _nms_case(rng, 900, 0, 0, 640, 80, cls_vals=[1, 2.5, 4])], 0.5),
+        ("negative_threshold", [_nms_case(rng, 600, 3, 0, 640, 20)], -0.1),
+        ("sparse_classes", [_nms_case(rng, 2200, 0, -3, 643, 50, cls_vals=[2, 7, 8, 200], ties=True)], 0.6),
+    ]
+    # a hand-made cross-class suppression: class 0 [100,100,700,700] and class 1 [-501,-501,99,99] meet after the offset of 701
+    quirk = np.zeros((300, 7), np.float32)
+    quirk[:, :] = _nms_case(rng, 300, 2, 100, 600, 30)
+    quirk[0] = [100, 100, 700, 700, 0.99, 1.0, 0]
+    quirk[1] = [-501, -501, 99, 99, 0.98, 1.0, 1]
+    cases.append(("quirk", [quirk], 0.5))
+    for name, imgs, thr in cases:
+        B, A = len(imgs), max(max(im.shape[0] for im in imgs), 300)
+        cand = np.zeros((B, A, 7), np.float32)
+        for b, im in enumerate(imgs):
+            cand[b, :im.shape[0]] = im
+        counts = [im.shape[0] for im in imgs]
+        keep = bbox.nms_keep_indices(torch.from_numpy(cand).to(DEV), torch.tensor(counts, dtype=torch.int32, device=DEV), thr)
+        for b, im in enumerate(imgs):
+            ref = orc.batched_nms_reference(im[:, :4], im[:, 4] * im[:, 5], im[:, 6], thr)
+            assert np.array_equal(np.asarray(keep[b], np.int64), np.asarray(ref, np.int64)), (name, b, len(keep[b]), len(ref))
+        if name == "quirk":
+            assert 1 not in list(keep[0])   # suppressed ACROSS classes, as in the reference

@@ -69,7 +69,7 @@ def test_nms_noalloc_matches_nms_on_two_calls_in_a_row():
 def test_nms_noalloc_rejects_sizes_beyond_its_scratch():
     from ccnet_amd import _lib
     lib = _lib.lib()
-    B, n = 16, 8192  # 16 x 8192 x 128 words of bitmask alone = 128 MiB
+    B, n = 16, 20000  # 16 x (8 W^2 + 72 W) words of bitmask panel, W = 313: 100 MiB
     assert int(lib.ccnet_nms_workspace_bytes(B, n)) > int(lib.ccnet_nms_noalloc_max_bytes())
     cand = torch.zeros(B, n, 7, device="cuda")
     counts = torch.zeros(B, dtype=torch.int32, device="cuda")
