@@ -40,6 +40,9 @@ def lib():
         L.ccnet_device_count.restype = i32
         L.ccnet_conv_pack_dims.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
         L.ccnet_conv2d.argtypes = [C.POINTER(ConvDesc), vp]
+        L.ccnet_csp_fused_weight_elems.argtypes = [i32, i32]
+        L.ccnet_csp_fused_weight_elems.restype = sz
+        L.ccnet_csp_fused.argtypes = [C.POINTER(Slice), i32, i32, i32, i32, i32, i32, i32, vp, vp, Slice, vp]
         L.ccnet_stem_conv.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, Slice, i32, vp]
         L.ccnet_dwconv3x3.argtypes = [Slice, i32, i32, i32, i32, vp, vp, Slice, vp]
         L.ccnet_sppf_pool.argtypes = [Slice, i32, i32, i32, i32, vp]

@@ -276,6 +276,22 @@ class Compiler:
         w1, b1 = self.folded(p + ".conv1")
         w2, b2 = self.folded(p + ".conv2")
         h = w1.shape[0]
+        x0 = ins[0]
+        # (hidden 64 is built and tested too, but measures slower than the five launches at 80^2 -- 185-280 us against ~200 us --
+        # so only the 160^2 layer, hidden 32, takes the fused kernel: 392 -> 233 us at bs64)
+        if (self.dtype == BF16 and n == 1 and not amff and (h == 32 or (h == 64 and os.environ.get("CCNET_FUSED_CSP_ALL", "0") == "1")) and self.act == "silu" and x0.H % 8 == 0 and x0.W % 16 == 0
+                and all(t.C % 64 == 0 and t.shift <= 1 for t in ins) and self.sd[p + ".conv3.conv.weight"].shape[0] == 2 * h
+                and os.environ.get("CCNET_NO_FUSED_CSP", "0") == "0"):
+            # the whole layer in one launch: x_1, x_2 and the bottleneck's hidden map never leave LDS (csp_fused.hip)
+            q = p + ".m.0"
+            wa, ba = self.folded(q + ".conv1")
+            wb, bb = self.folded(q + ".conv2")
+            w3, b3 = self.folded(p + ".conv3")
+            pk = ops.PackedCsp(torch.cat([w1, w2], 0), torch.cat([b1, b2], 0), wa, ba, wb, bb, w3, b3, self.dev)
+            self.keep.append(pk)
+            out = self.new(2 * h, x0.H, x0.W)
+            ops.csp_fused([t.sl() for t in ins], pk, self.B, x0.H, x0.W, shortcut, self.act, out.sl())
+            return out
         cat = self.conv_w(torch.cat([w1, w2], 0), torch.cat([b1, b2], 0), ins, 1, 0, self.act)  # [x_1 | x_2]
         x1 = cat.part(0, h)
         for i in range(n):

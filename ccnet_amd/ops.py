@@ -90,6 +90,27 @@ def conv2d(ins, pc, B, H, W, stride, pad, out, act="none", residual=None, out_dt
     return d.Ho, d.Wo
 
 
+class PackedCsp:
+    """Fragment-packed weights of one CSPLayer with a single bottleneck for ccnet_csp_fused (include/ccnet_hip.h):
+    mats = [(w OIHW fp64, b fp64)] for [conv1;conv2], bottleneck conv1, bottleneck conv2 (3x3), conv3."""
+
+    def __init__(self, w12, b12, wb1, bb1, wb2, bb2, w3, b3, device):
+        h = wb1.shape[0]
+        self.hidden, self.cin = h, w12.shape[1]
+        mats = [w12.reshape(2 * h, -1), wb1.reshape(h, h), wb2.permute(0, 2, 3, 1).reshape(h, 9 * h), w3.reshape(w3.shape[0], 2 * h)]
+        assert w12.shape[0] == 2 * h and w3.shape[0] == 2 * h and tuple(wb2.shape) == (h, h, 3, 3)
+        frags = torch.cat([_mfma_frags(m.to(torch.float64)).reshape(-1) for m in mats])
+        assert frags.numel() == int(lib().ccnet_csp_fused_weight_elems(self.cin, h))
+        self.weight = frags.to(torch.bfloat16).to(device).contiguous()
+        self.bias = torch.cat([b12, bb1, bb2, b3]).to(torch.float32).to(device).contiguous()
+
+
+def csp_fused(ins, pk, B, H, W, shortcut, act, out):
+    arr = (Slice * len(ins))(*ins)
+    check(lib().ccnet_csp_fused(arr, len(ins), B, H, W, pk.hidden, 1 if shortcut else 0, ACT[act], pk.weight.data_ptr(), pk.bias.data_ptr(),
+                                out, stream_ptr()))
+
+
 def stem_conv(x, w, b, cout, act, out, out_dtype):
     B, _, H, W = x.shape
     check(lib().ccnet_stem_conv(x.data_ptr(), B, H, W, w.data_ptr(), b.data_ptr(), cout, ACT[act], out, out_dtype, stream_ptr()))

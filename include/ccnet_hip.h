@@ -80,6 +80,19 @@ typedef struct {
 int ccnet_conv_pack_dims(int dtype, int Cout, int K, int* Cout_pad, int* Kpad);
 int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream);
 
+/* ---- a whole CSPLayer with one bottleneck in one launch (bf16) ---------------------------------------------
+ * Replaces CSPLayer.forward with n = 1 (network/model_block.py:86-116) and the Bottleneck inside it (:193-218):
+ *   x_1 = conv1(x); x_2 = conv2(x); x_1 = [x_1 +] conv_b2(conv_b1(x_1)); out = conv3(cat(x_1, x_2))
+ * every conv a BaseConv (BN folded, SiLU); x = channel concat of in[0..nseg-1] (each a multiple of 64 channels, may carry
+ * an upsampling shift).  hidden = 32 or 64; out has 2*hidden channels; H % 8 == 0 and W % 16 == 0.  Intermediates are
+ * rounded to bf16 where the separate launches round them.  weights_dev: bf16 MFMA fragments of
+ * [conv1;conv2] (2h x Cin) | conv_b1 (h x h) | conv_b2 (h x 9h, K = (ky*3+kx)*h + c) | conv3 (2h x 2h), each
+ * [n-tile][k-step][64 lanes][8] (ccnet_amd/ops.py:pack_csp), ccnet_csp_fused_weight_elems(cin, hidden) elements;
+ * bias_dev: fp32 [2h | h | h | 2h].  Anything else: CCNET_EINVAL (callers use ccnet_conv2d per layer). */
+size_t ccnet_csp_fused_weight_elems(int cin, int hidden);
+int ccnet_csp_fused(const ccnet_slice* in, int nseg, int B, int H, int W, int hidden, int shortcut, int act,
+                    const void* weights_dev, const float* bias_dev, ccnet_slice out, ccnet_stream stream);
+
 /* ---- network stem: 6x6 stride-2 pad-2 conv on the NCHW fp32 image, folded BN, activation ------------------
  * Replaces FocusReplaceConv (network/net_deploy.py:41) and SpaceToDepth(3,..)+BaseConv k3 (network/net.py:40)
  * in its 6x6 form.  x_dev: fp32 [B][3][H][W] (the tensor the reference's callers build, tools/demo.py:56-65).

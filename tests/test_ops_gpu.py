@@ -671,3 +671,90 @@ def test_nms_class_groups_bit_exact():
             assert np.array_equal(np.asarray(keep[b], np.int64), np.asarray(ref, np.int64)), (name, b, len(keep[b]), len(ref))
         if name == "quirk":
             assert 1 not in list(keep[0])   # suppressed ACROSS classes, as in the reference
+
+
+# ------------------------------------------------------------------------------------------ fused CSP layer
+def _csp_state(prefix, cin, h, gen):
+    """state_dict of a CSPLayer(cin, 2h, n=1) with non-trivial BN statistics (reference key names, model_block.py:86-116)."""
+    sd = {}
+
+    def base(p, co, ci, k):
+        sd[p + ".conv.weight"] = torch.randn(co, ci, k, k, generator=gen) * (1.5 / math.sqrt(ci * k * k))
+        sd[p + ".bn.weight"] = torch.rand(co, generator=gen) * 0.5 + 0.75
+        sd[p + ".bn.bias"] = torch.randn(co, generator=gen) * 0.2
+        sd[p + ".bn.running_mean"] = torch.randn(co, generator=gen) * 0.1
+        sd[p + ".bn.running_var"] = torch.rand(co, generator=gen) * 0.5 + 0.5
+
+    base(prefix + ".conv1", h, cin, 1)
+    base(prefix + ".conv2", h, cin, 1)
+    base(prefix + ".conv3", 2 * h, 2 * h, 1)
+    base(prefix + ".m.0.conv1", h, h, 1)
+    base(prefix + ".m.0.conv2", h, h, 3)
+    return sd
+
+
+@pytest.mark.parametrize("h,segs,up,shortcut,B,H,W", [
+    (32, (64,), False, True, 3, 16, 32),       # dark2.1 of network/net.py
+    (64, (128,), False, True, 2, 24, 48),      # dark3.1
+    (64, (128, 128), True, False, 2, 16, 32),  # C3_p3: cat(upsample(fpn1), gate2)
+    (32, (64, 64), True, False, 1, 8, 16),     # one tile: every halo pixel is outside the image
+    (64, (64, 192), False, False, 1, 40, 16),
+])
+def test_csp_fused_matches_layerwise_and_torch(h, segs, up, shortcut, B, H, W):
+    """ccnet_csp_fused (one launch per CSPLayer, csrc/csp_fused.hip) against (a) the same layer as five ccnet_conv2d launches --
+    same bf16 rounding points, so only the accumulation order differs -- and (b) CSPLayer.forward in torch fp32
+    (model_block.py:86-116, 193-218) on the bf16-rounded input, at bf16 tolerance."""
+    import os
+    import torch.nn.functional as F
+    from ccnet_amd import ops
+    from ccnet_amd._lib import BF16
+    from ccnet_amd.network import graph
+    gen = torch.Generator().manual_seed(h * 1000 + sum(segs) + H)
+    cin = sum(segs)
+    sd = _csp_state("blk", cin, h, gen)
+    xs = []
+    for i, c in enumerate(segs):
+        hh, ww = (H // 2, W // 2) if (up and i == 0) else (H, W)
+        xs.append((torch.randn(B, hh, ww, c, generator=gen) * 0.8).to(torch.bfloat16))
+
+    def run(fused):
+        os.environ["CCNET_NO_FUSED_CSP"] = "0" if fused else "1"
+        os.environ["CCNET_FUSED_CSP_ALL"] = "1"   # hidden 64 too (the networks only send hidden 32 to the fused kernel)
+        try:
+            comp = graph.Compiler(sd, {}, B, H, W, BF16, torch.device(DEV), "silu")
+            ins = []
+            for i, x in enumerate(xs):
+                t = graph.T(x.to(DEV).contiguous(), 0, x.shape[-1], x.shape[1], x.shape[2])
+                ins.append(t.up() if (up and i == 0) else t)
+            n0 = []
+            orig = ops.csp_fused
+            ops.csp_fused = lambda *a, **k: (n0.append(1), orig(*a, **k))[1]
+            try:
+                out = comp.csp("blk", ins, 1, shortcut)
+            finally:
+                ops.csp_fused = orig
+            torch.cuda.synchronize()
+            assert bool(n0) == fused, "fused kernel %s" % ("not taken" if fused else "taken")
+            return out.buf[..., out.coff:out.coff + out.C].float().cpu()
+        finally:
+            os.environ.pop("CCNET_NO_FUSED_CSP", None)
+            os.environ.pop("CCNET_FUSED_CSP_ALL", None)
+
+    got, layer = run(True), run(False)
+    # torch fp32 reference
+    def bc(p, x, k):
+        w, b = ops.fold_bn(sd[p + ".conv.weight"], (sd[p + ".bn.weight"], sd[p + ".bn.bias"], sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"]))
+        return F.silu(F.conv2d(x, w.float(), b.float(), padding=(k - 1) // 2))
+    parts = []
+    for i, x in enumerate(xs):
+        xf = x.float().permute(0, 3, 1, 2)
+        parts.append(F.interpolate(xf, scale_factor=2, mode="nearest") if (up and i == 0) else xf)
+    x = torch.cat(parts, 1)
+    x1, x2 = bc("blk.conv1", x, 1), bc("blk.conv2", x, 1)
+    y = bc("blk.m.0.conv2", bc("blk.m.0.conv1", x1, 1), 3)
+    x1 = y + x1 if shortcut else y
+    ref = bc("blk.conv3", torch.cat([x1, x2], 1), 1).permute(0, 2, 3, 1)
+    rms = lambda a, b: float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+    assert got.shape == ref.shape
+    assert rms(got, layer) < 4e-3 and float((got - layer).abs().max()) < 0.06, (rms(got, layer), float((got - layer).abs().max()))
+    assert rms(got, ref) < 1.5e-2 and rms(layer, ref) < 1.5e-2, (rms(got, ref), rms(layer, ref))
