@@ -66,44 +66,68 @@ def decode_outputs(outputs, input_shape):
 _nmax_guess = {}
 
 
-def _filter_and_nms(pred, num_classes, conf_thres, nms_thres, image_hw):
-    """pred (B, A, 5+nc) fp32 CUDA contiguous.  Returns (det_host (B,nmax,7), nkeep_host (B,)) as numpy arrays.
+class PendingDetections:
+    """Detections of one batch whose kernels and device->host copy have been submitted (post_process_async).  `result()` waits
+    for the copy and returns what post_process returns.  Holding the object keeps every buffer the kernels use alive."""
 
-    NMS needs the largest per-image candidate count to size its rows.  The first call for a (B, A, device) waits for the
-    counts; later calls launch NMS at once with an estimate from the previous call (1.25x, rounded up to 64) and fetch rows,
-    keep counts and candidate counts in ONE device->host copy.  If an image turned out to have more candidates than the
-    estimate (the kernels cut, never overrun), NMS is launched again with the exact maximum -- results do not depend on the
-    estimate, only the number of host round trips does."""
-    B, A, _ = pred.shape
-    dev = pred.device
-    key = (B, A, str(dev))
-    cand = torch.empty(B, A, 7, dtype=torch.float32, device=dev)
-    with _cache_lock:
-        nmax = _nmax_guess.get(key)
-    if nmax is None:
-        both = None
-        counts = torch.empty(B, dtype=torch.int32, device=dev)
-        ops.filter_candidates(pred, num_classes, conf_thres, cand, counts)
-        nmax = min(max(int(counts.cpu().max()), 1), A)  # waits for the filter kernel
-    else:
-        nmax = min(nmax, A)
-        both = _result_buffer(B, nmax, dev)
-        counts = both[B * nmax * 7 + B:].view(torch.int32)  # the filter kernel writes its counts straight into the result buffer
-        ops.filter_candidates(pred, num_classes, conf_thres, cand, counts)
-    while True:
-        if both is None:
-            both = _result_buffer(B, nmax, dev)
-            both[B * nmax * 7 + B:].view(torch.int32).copy_(counts)
-        _nms(cand, counts, nmax, nms_thres, image_hw, both)
-        host = both.cpu().numpy()
-        cmax = int(host[B * nmax * 7 + B:].view(np.int32).max())
+    def __init__(self, pred, num_classes, conf_thres, nms_thres, image_hw):
+        self._done = None
+        B, A, _ = pred.shape
+        dev = pred.device
+        self.B, self.A, self.key = B, A, (B, A, str(dev))
+        self.pred, self.nms_thres, self.image_hw = pred, nms_thres, image_hw
+        self.cand = torch.empty(B, A, 7, dtype=torch.float32, device=dev)
         with _cache_lock:
-            if len(_nmax_guess) >= 64:
-                _nmax_guess.clear()
-            _nmax_guess[key] = min(A, max(64, -(-(cmax + cmax // 4) // 64) * 64))
-        if cmax <= nmax:
-            return host[:B * nmax * 7].reshape(B, nmax, 7), host[B * nmax * 7:B * nmax * 7 + B].view(np.int32)
-        nmax, both = min(cmax, A), None
+            nmax = _nmax_guess.get(self.key)
+        if nmax is None:
+            # first call for this (B, A, device): wait for the counts, then run NMS with the exact maximum
+            self.counts = torch.empty(B, dtype=torch.int32, device=dev)
+            ops.filter_candidates(pred, num_classes, conf_thres, self.cand, self.counts)
+            self.nmax = min(max(int(self.counts.cpu().max()), 1), A)
+            self.both = _result_buffer(B, self.nmax, dev)
+            self.both[B * self.nmax * 7 + B:].view(torch.int32).copy_(self.counts)
+        else:
+            self.nmax = min(nmax, A)
+            self.both = _result_buffer(B, self.nmax, dev)
+            # the filter kernel writes its counts straight into the result buffer
+            self.counts = self.both[B * self.nmax * 7 + B:].view(torch.int32)
+            ops.filter_candidates(pred, num_classes, conf_thres, self.cand, self.counts)
+        self._submit()
+
+    def _submit(self):
+        _nms(self.cand, self.counts, self.nmax, self.nms_thres, self.image_hw, self.both)
+        self.host = torch.empty(self.both.numel(), dtype=torch.float32, pin_memory=True)
+        self.host.copy_(self.both, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def result(self):
+        if self._done is not None:
+            return self._done
+        B, A = self.B, self.A
+        while True:
+            self.event.synchronize()
+            nmax = self.nmax
+            host = self.host.numpy()
+            cmax = int(host[B * nmax * 7 + B:].view(np.int32).max())
+            with _cache_lock:
+                if len(_nmax_guess) >= 64:
+                    _nmax_guess.clear()
+                _nmax_guess[self.key] = min(A, max(64, -(-(cmax + cmax // 4) // 64) * 64))
+            if cmax <= nmax:
+                det = host[:B * nmax * 7].reshape(B, nmax, 7)
+                nk = host[B * nmax * 7:B * nmax * 7 + B].view(np.int32)
+                self._done = [det[b, :nk[b]].copy() for b in range(B)]
+                self.pred = self.cand = self.both = self.counts = self.host = None
+                return self._done
+            # an image had more candidates than the rows NMS was given (the kernels cut, never overrun): once more, exact
+            with torch.cuda.device(self.cand.device):
+                counts = self.counts.clone()
+                self.nmax = min(cmax, A)
+                self.both = _result_buffer(B, self.nmax, self.cand.device)
+                self.both[B * self.nmax * 7 + B:].view(torch.int32).copy_(counts)
+                self.counts = counts
+                self._submit()
 
 
 def _result_buffer(B, nmax, dev):
@@ -140,16 +164,36 @@ def nms_keep_indices(cand, counts, nms_thres):
     return [ki[b, :nk[b]].astype(np.int64) for b in range(B)]
 
 
+def post_process_async(prediction, num_classes, input_shape, image_info, conf_thres=0.5, nms_thres=0.4):
+    """post_process with the wait taken out: submits filter, NMS and the device->host copy of the result on the current stream
+    and returns a PendingDetections; `.result()` gives post_process's return value.  A serving loop that launches the next
+    batch's forward before collecting this batch's detections keeps the GPU busy through the host round trip (bench.py).
+
+    NMS needs the largest per-image candidate count to size its rows.  The first call for a (B, A, device) waits for the
+    counts; later calls launch NMS at once with an estimate from the previous call (1.25x, rounded up to 64) and fetch rows,
+    keep counts and candidate counts in ONE device->host copy.  If an image turned out to have more candidates than the
+    estimate, NMS is launched again with the exact maximum when the result is collected -- results do not depend on the
+    estimate, only the number of host round trips does."""
+    _require_cuda(prediction, "post_process")
+    B, A = int(prediction.shape[0]), int(prediction.shape[1])
+    if A == 0 or B == 0:
+        return _Ready([None for _ in range(B)])
+    pred = prediction.float().contiguous()
+    hw = _image_hw(tuple((int(image_info[i][2]), int(image_info[i][1])) for i in range(B)), pred.device)
+    with torch.cuda.device(pred.device):
+        return PendingDetections(pred, num_classes, conf_thres, nms_thres, hw)
+
+
+class _Ready:
+    def __init__(self, value):
+        self._value = value
+
+    def result(self):
+        return self._value
+
+
 def post_process(prediction, num_classes, input_shape, image_info, conf_thres=0.5, nms_thres=0.4):
     """Same contract as the reference: list (len B) of float32 arrays (n_i, 7) with columns
     [top, left, bottom, right, obj_conf, class_conf, class_id] in original-image pixels; (0,7) when nothing survives;
     None entries only when there are no anchors at all.  image_info[i] = [name, image_w, image_h] (tools/demo.py:52)."""
-    _require_cuda(prediction, "post_process")
-    B, A = int(prediction.shape[0]), int(prediction.shape[1])
-    if A == 0 or B == 0:
-        return [None for _ in range(B)]
-    pred = prediction.float().contiguous()
-    hw = _image_hw(tuple((int(image_info[i][2]), int(image_info[i][1])) for i in range(B)), pred.device)
-    with torch.cuda.device(pred.device):
-        det_h, nk = _filter_and_nms(pred, num_classes, conf_thres, nms_thres, hw)
-    return [det_h[b, :nk[b]].copy() for b in range(B)]
+    return post_process_async(prediction, num_classes, input_shape, image_info, conf_thres, nms_thres).result()
