@@ -23,6 +23,9 @@ namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef CSP_WAVES
+#define CSP_WAVES 4
+#endif
 constexpr int TH = 8, TW = 16, PW = TW + 2, PROWS = (TH + 2) * PW, MROWS = 192;  // 180 patch pixels, 12 m-tiles
 constexpr int XB_BYTES = MROWS * 128;                                            // one 64-channel chunk of the patch
 
@@ -55,6 +58,11 @@ __device__ __forceinline__ f32x4 mfma(const u32x4& a, const u32x4& b, const f32x
 
 // Where a wave finds its weight fragments: fragment i of the packed blob is 64 lanes x 16 bytes, in global memory (L2-resident)
 // or, when the whole blob fits beside the activations, in LDS (staged once per persistent workgroup).
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 template <bool WLDS>
 struct WSrc {
     const u32x4* g;
@@ -111,19 +119,22 @@ __device__ unsigned long long g_csp_stamps[8];
 #define CSTAMP(i)
 #endif
 
-constexpr int NLD = (PROWS * 8 + 255) / 256;  // 16-byte pieces of one 64-channel patch chunk per thread
 
 // H16 = hidden / 16 (2 or 4).  LDS: XB | P1 (x_1 patch, later x_1' on its inner rows) | P2 (x_2, inner pixels) [| weights]
-template <int H16, bool SHORTCUT, bool WLDS>
-__global__ __launch_bounds__(256, 2) void csp_fused_kernel(const CspP p) {
+// NWV waves per workgroup (4 or 8); every stage splits its (m-tile, n-tile) grid over them, n first.
+template <int H16, bool SHORTCUT, bool WLDS, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV / 2) void csp_fused_kernel(const CspP p) {
     constexpr int HID = 16 * H16, RB = 2 * HID, KH = HID / 32;  // bytes per row of the hidden-width images; k-steps of a hidden-wide K
-    constexpr int NTW = H16 / 2;                                 // stage 1: n-tiles per wave of the 2*H16 of [x_1 | x_2]
+    constexpr int NTH = NWV * 64;
+    constexpr int NLD = (PROWS * 8 + NTH - 1) / NTH;            // 16-byte pieces of one 64-channel patch chunk per thread
+    // stage 1: the 2*H16 n-tiles of [x_1 | x_2] over the waves; WPN waves share an n-tile and split its m-tiles
+    constexpr int N1 = 2 * H16, NTW = N1 >= NWV ? N1 / NWV : 1, WPN = N1 >= NWV ? 1 : NWV / N1, M1A = 12 / WPN, M1B = 8 / WPN;
     extern __shared__ __align__(16) unsigned char lds[];
     unsigned char* XB = lds;
     unsigned char* P1 = lds + XB_BYTES;
     unsigned char* P2 = P1 + MROWS * RB;
     unsigned char* WL = P2 + 128 * RB;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, px16 = lane & 15, kg = lane >> 4;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, px16_0 = lane & 15, kg_0 = lane >> 4;
     const int KS1 = p.cin / 32;
     // first fragment of the four weight matrices in the blob, and their biases
     const int f12 = 0, fb1 = 2 * H16 * KS1, fb2 = fb1 + H16 * KH, f3 = fb2 + H16 * 9 * KH;
@@ -134,7 +145,8 @@ __global__ __launch_bounds__(256, 2) void csp_fused_kernel(const CspP p) {
     const WSrc<WLDS> w{p.w, WL};
     if constexpr (WLDS) {
         const int nfr16 = (f3 + 2 * H16 * 2 * KH) * 64;
-        for (int i = t; i < nfr16; i += 256) ((u32x4*)WL)[i] = p.w[i];
+        for (int i = t; i < nfr16; i += NTH) ((u32x4*)WL)[i] = p.w[i];
+        __syncthreads();  // the first fragments are read before the tile loop's first barrier
     }
 
     // the patch chunk (kc) of a tile: global -> registers (xload), registers -> XB (xstore)
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void csp_fused_kernel(const CspP p) {
         const int cseg = ch0 - (sgi ? p.seg[0].C : 0);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int idx = t + i * 256;
+            const int idx = t + i * NTH;
             const int r = idx >> 3, c = idx & 7;
             const int py = (r * 3641) >> 16, pxx = r - py * PW;  // r / 18 for r < 180
             const int gy = y0 - 1 + py, gx = x0 - 1 + pxx;
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void csp_fused_kernel(const CspP p) {
     auto xstore = [&]() {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int idx = t + i * 256;
+            const int idx = t + i * NTH;
             if (idx < PROWS * 8) *(u32x4*)(XB + lds_off<128>(idx >> 3, idx & 7)) = xv[i];
         }
     };
@@ -172,20 +184,25 @@ __global__ __launch_bounds__(256, 2) void csp_fused_kernel(const CspP p) {
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
     const int nchunks = p.cin / 64;
-    const int nt0 = wave * NTW;   // stage 1: first n-tile of the wave among the 2*H16 of [x_1 | x_2]
-    const bool isx1 = nt0 < H16;  // waves 0,1: x_1 on the whole patch; waves 2,3: x_2 on the inner pixels
+    const int nt0 = (wave / WPN) * NTW;  // stage 1: first n-tile of the wave among the 2*H16 of [x_1 | x_2]
+    const int mp1 = wave % WPN;          // and its share of that n-tile's m-tiles
+    const bool isx1 = nt0 < H16;         // x_1 on the whole patch (12 m-tiles), x_2 on the inner pixels (8)
     if (blockIdx.x < p.ntiles) xload(blockIdx.x, 0);
     for (unsigned tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int tx = (int)(tile % (unsigned)p.tiles_x);
         const int rest = (int)(tile / (unsigned)p.tiles_x);
         const int ty = rest % p.tiles_y, b = rest / p.tiles_y;
         const int y0 = ty * TH, x0 = tx * TW;
+        // The swizzled LDS addresses below are the same for every tile; left alone, the compiler hoists dozens of them out of
+        // the tile loop and spills them.  Laundered lane terms make it recompute them (a few VALU instructions per use).
+        // (hidden 64 only: hidden 32 has the registers to keep them)
+        const int px16 = H16 == 4 ? opaque(px16_0) : px16_0, kg = H16 == 4 ? opaque(kg_0) : kg_0;
 
         // ---- stage 1: [x_1 | x_2] over K = cin, 64 channels at a time through XB.  Chunk 0 was fetched during the previous
         // tile's stage 4 (XB has been free since that tile's stage 3 ended).
-        f32x4 acc1[12][NTW];
+        f32x4 acc1[M1A][NTW];
 #pragma unroll
-        for (int m = 0; m < 12; ++m)
+        for (int m = 0; m < M1A; ++m)
 #pragma unroll
             for (int n = 0; n < NTW; ++n) acc1[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int kc = 0; kc < nchunks; ++kc) {
@@ -199,15 +216,15 @@ __global__ __launch_bounds__(256, 2) void csp_fused_kernel(const CspP p) {
             __syncthreads();
             CSTAMP(0);
             if (isx1)
-                mm<12, NTW, 2, 2>(acc1, r1, w, f12 + nt0 * KS1 + kc * 2, KS1, lane,
-                                  [&](int m, int ks) { return XB + lds_off<128>(m * 16 + px16, ks * 4 + kg); });
+                mm<M1A, NTW, 2, 2>(acc1, r1, w, f12 + nt0 * KS1 + kc * 2, KS1, lane,
+                                   [&](int m, int ks) { return XB + lds_off<128>((mp1 * M1A + m) * 16 + px16, ks * 4 + kg); });
             else
-                mm<8, NTW, 2, 2>(acc1, r1, w, f12 + nt0 * KS1 + kc * 2, KS1, lane,
-                                 [&](int m, int ks) { return XB + lds_off<128>((m + 1) * PW + 1 + px16, ks * 4 + kg); });
+                mm<M1B, NTW, 2, 2>(acc1, r1, w, f12 + nt0 * KS1 + kc * 2, KS1, lane,
+                                   [&](int m, int ks) { return XB + lds_off<128>((mp1 * M1B + m + 1) * PW + 1 + px16, ks * 4 + kg); });
             CSTAMP(1);
         }
         // stage 2's fragments travel under epilogue 1
-        constexpr int NSPLIT2 = H16 >= 4 ? 4 : 2, MT2 = 12 / (4 / NSPLIT2);
+        constexpr int NSPLIT2 = H16 < NWV ? H16 : NWV, MT2 = 12 / (NWV / NSPLIT2);
         const int nt2 = wave % NSPLIT2, m02 = (wave / NSPLIT2) * MT2;
         u32x4 r2[KH][1];
         preload<1, KH, KH>(r2, w, fb1 + nt2 * KH, KH, lane);
@@ -218,13 +235,13 @@ __global__ __launch_bounds__(256, 2) void csp_fused_kernel(const CspP p) {
             const float4 bv = *(const float4*)(b12 + ch);
             if (isx1) {
 #pragma unroll
-                for (int m = 0; m < 12; ++m)
-                    *(uint2*)(P1 + lds_off<RB>(m * 16 + px16, ch >> 3) + (ch & 7) * 2) = silu4(acc1[m][n], bv);
+                for (int m = 0; m < M1A; ++m)
+                    *(uint2*)(P1 + lds_off<RB>((mp1 * M1A + m) * 16 + px16, ch >> 3) + (ch & 7) * 2) = silu4(acc1[m][n], bv);
             } else {
                 const int c2 = ch - HID;
 #pragma unroll
-                for (int m = 0; m < 8; ++m)
-                    *(uint2*)(P2 + lds_off<RB>(m * 16 + px16, c2 >> 3) + (c2 & 7) * 2) = silu4(acc1[m][n], bv);
+                for (int m = 0; m < M1B; ++m)
+                    *(uint2*)(P2 + lds_off<RB>((mp1 * M1B + m) * 16 + px16, c2 >> 3) + (c2 & 7) * 2) = silu4(acc1[m][n], bv);
             }
         }
         __syncthreads();
@@ -232,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void csp_fused_kernel(const CspP p) {
 
         // ---- stage 2: t = SiLU(Wb1 x_1 + b) on the patch -> T (= XB), zero outside the image
         unsigned char* T = XB;
-        constexpr int NSPLIT3 = H16 / 2, MT3 = 8 / (4 / NSPLIT3), NKS3 = 9 * KH, D3 = 4;
+        constexpr int NSPLIT3 = H16 / 2, MT3 = 8 / (NWV / NSPLIT3), NKS3 = 9 * KH, D3 = 4;
         const int nh3 = wave % NSPLIT3, m03 = (wave / NSPLIT3) * MT3;
         const int fw3 = fb2 + nh3 * 2 * NKS3;
         u32x4 r3[D3][2];
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void csp_fused_kernel(const CspP p) {
         CSTAMP(3);
 
         // ---- stage 3: x_1' = SiLU(Wb2 * t + b) [+ x_1], 3x3 taps as shifted rows of T; in place over P1's inner rows
-        constexpr int NT4 = H16, MT4 = 4, NKS4 = 2 * KH, D4 = NKS4 < 2 ? NKS4 : 2;  // stage 4: 2*H16 n-tiles, 8 m-tiles over 2 x 2 waves
+        constexpr int NT4 = H16, MT4 = 8 / (NWV / 2), NKS4 = 2 * KH, D4 = NKS4 < 2 ? NKS4 : 2;  // stage 4: 2*H16 n-tiles in two halves
         const int nh4 = wave & 1, m04 = (wave >> 1) * MT4;
         const int fw4 = f3 + nh4 * NT4 * NKS4;
         u32x4 r4[D4][NT4];
@@ -340,9 +357,9 @@ __global__ __launch_bounds__(256, 2) void csp_fused_kernel(const CspP p) {
     }
 }
 
-template <int H16, bool SHORTCUT, bool WLDS>
+template <int H16, bool SHORTCUT, bool WLDS, int NWV = CSP_WAVES>
 int launch_csp(const CspP& p, hipStream_t st, int wbytes) {
-    auto kernel = csp_fused_kernel<H16, SHORTCUT, WLDS>;
+    auto kernel = csp_fused_kernel<H16, SHORTCUT, WLDS, NWV>;
     const int LDS = XB_BYTES + MROWS * 32 * H16 + 128 * 32 * H16 + (WLDS ? wbytes : 0);
     static int cached[16] = {0}, cached_lds[16] = {0};
     int dev = 0;
@@ -350,14 +367,14 @@ int launch_csp(const CspP& p, hipStream_t st, int wbytes) {
     if (cached[dev] == 0 || cached_lds[dev] != LDS) {
         CC_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, 256, LDS) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, NWV * 64, LDS) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         cached[dev] = per_cu * cus;
         cached_lds[dev] = LDS;
     }
     int grid = cached[dev];
     if ((unsigned)grid > p.ntiles) grid = (int)p.ntiles;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), LDS, st, p);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(NWV * 64), LDS, st, p);
     CC_LAUNCH_CHECK();
     return CCNET_OK;
 }

@@ -277,9 +277,10 @@ class Compiler:
         w2, b2 = self.folded(p + ".conv2")
         h = w1.shape[0]
         x0 = ins[0]
-        # (hidden 64 is built and tested too, but measures slower than the five launches at 80^2 -- 185-280 us against ~200 us --
-        # so only the 160^2 layer, hidden 32, takes the fused kernel: 392 -> 233 us at bs64)
-        if (self.dtype == BF16 and n == 1 and not amff and (h == 32 or (h == 64 and os.environ.get("CCNET_FUSED_CSP_ALL", "0") == "1")) and self.act == "silu" and x0.H % 8 == 0 and x0.W % 16 == 0
+        # hidden 32 (160^2 at 640: 392 -> 233 us at bs64) and hidden 64 on one input tensor (dark3.1 at 80^2: 198 -> 164 us); with two
+        # input segments (C3_p3) hidden 64 only equals the five launches, so it is not taken (CCNET_FUSED_CSP_ALL=1 forces it)
+        wide_ok = h == 64 and (len(ins) == 1 or os.environ.get("CCNET_FUSED_CSP_ALL", "0") == "1")
+        if (self.dtype == BF16 and n == 1 and not amff and (h == 32 or wide_ok) and self.act == "silu" and x0.H % 8 == 0 and x0.W % 16 == 0
                 and all(t.C % 64 == 0 and t.shift <= 1 for t in ins) and self.sd[p + ".conv3.conv.weight"].shape[0] == 2 * h
                 and os.environ.get("CCNET_NO_FUSED_CSP", "0") == "0"):
             # the whole layer in one launch: x_1, x_2 and the bottleneck's hidden map never leave LDS (csp_fused.hip)

@@ -1,5 +1,6 @@
 """Cycle stamps of the fused CSP kernel (library built with EXTRA_csp_fused=-DCSP_STAMP): share of wave 0's time per phase."""
 import ctypes as C, os, sys
+os.environ["CCNET_FUSED_CSP_ALL"] = "1"
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ccnet_amd import ops, _lib

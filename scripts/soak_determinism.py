@@ -1,5 +1,5 @@
 import sys, torch, numpy as np
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ccnet_amd import synth
 from ccnet_amd.network.net import Net
 from ccnet_amd.network.net_deploy import Net as NetD
