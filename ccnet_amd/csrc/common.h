@@ -51,17 +51,13 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float x) {
     __bf16 h = (__bf16)x;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return (uint32_t)__builtin_bit_cast(unsigned short, h);
 }
-// two floats -> one packed pair: a single v_cvt_pk_bf16_f32 (converting the halves one by one costs two conversions, a shift
-// and an OR; same round-to-nearest-even result)
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// Two floats -> one packed pair, each half converted on its own.  (The vector form -- __builtin_convertvector of a float2, one
+// v_cvt_pk_bf16_f32 with two sources instead of two conversions, a shift and an OR -- was tried in every epilogue: it made the
+// fused Transformer's in-place LayerNorm run-to-run different on tokens 48..63 (scripts/tf_det_probe.py; cured by an
+// instruction barrier in front of the conversion, not reproduced by an isolated pk_fma -> cvt_pk test), for 0.2 % of the step.
+// Not understood, so not used.)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-#ifdef CCNET_PACK_OLD
     return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
-#else
-    const f32x2_t f = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
-#endif
 }
 // 8 consecutive channels <-> fp32
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {

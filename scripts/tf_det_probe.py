@@ -1,0 +1,27 @@
+"""Run-to-run determinism of the fused Transformer alone, by depth (GPU box)."""
+import importlib, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ccnet_amd import ops, synth
+net = importlib.import_module("ccnet_amd.network.net").Net(0.33, 0.5, 6, "silu")
+sd = synth.synth_state_dict(net.state_dict(), seed=0, bn_calib="net")
+S, N = 64, 400
+src = (torch.randn(S * N, 256, device="cuda") * 0.7).to(torch.bfloat16)
+for ne, nd in ((1, 0), (0, 1), (6, 6)):
+    sd2 = dict(sd)
+    wst, pvec, fpw = ops.pack_transformer(sd2, "dark5.2.transformer", ne, nd, "cuda")
+    outs = []
+    for _ in range(4):
+        out = torch.full_like(src, 7.0)
+        ops.transformer_fused(src, 256, out, 256, S, N, wst, fpw, pvec, ne, nd)
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    diffs = [int((outs[0] != o).sum()) for o in outs[1:]]
+    rows = (outs[0] != outs[1]).any(dim=1).nonzero().flatten()
+    d01 = (outs[0] != outs[1])
+    svals = sorted(set((d01.any(dim=1).nonzero().flatten() // N).tolist()))
+    cols = d01.any(dim=0).nonzero().flatten().tolist()
+    mag = float((outs[0].float() - outs[1].float()).abs().max())
+    print("   tokens s differing: %s\n   columns differing: %d (%s..%s), max |diff| %.4f" % (svals, len(cols), cols[:4], cols[-4:], mag))
+    print("enc %d dec %d: differing elements vs run 0: %s; rows differing: %d, first rows %s, positions %s" % (
+        ne, nd, diffs, rows.numel(), rows[:6].tolist(), sorted(set((rows % N).tolist()))[:10]), flush=True)

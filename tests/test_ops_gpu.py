@@ -758,3 +758,26 @@ def test_csp_fused_matches_layerwise_and_torch(h, segs, up, shortcut, B, H, W):
     assert got.shape == ref.shape
     assert rms(got, layer) < 4e-3 and float((got - layer).abs().max()) < 0.06, (rms(got, layer), float((got - layer).abs().max()))
     assert rms(got, ref) < 1.5e-2 and rms(layer, ref) < 1.5e-2, (rms(got, ref), rms(layer, ref))
+
+
+def test_transformer_fused_is_run_to_run_identical():
+    """The fused Transformer at the headline shape (S = 64, N = 400) must give bit-identical outputs on repeated launches, for
+    the decoder alone (cross-attention stages the encoder memory by LDS-DMA) and for the full 6 + 6 stack.  A build whose bf16
+    packing used the vector conversion failed exactly this (tokens 48..63, csrc/common.h:pack_bf16x2)."""
+    import importlib
+    from ccnet_amd import ops, synth
+    net = importlib.import_module("ccnet_amd.network.net").Net(0.33, 0.5, 6, "silu")
+    sd = synth.synth_state_dict(net.state_dict(), seed=0, bn_calib="net")
+    S, N = 64, 400
+    g = torch.Generator().manual_seed(3)
+    src = (torch.randn(S * N, 256, generator=g) * 0.7).to(DEV, torch.bfloat16)
+    for ne, nd in ((0, 1), (6, 6)):
+        wst, pvec, fpw = ops.pack_transformer(sd, "dark5.2.transformer", ne, nd, DEV)
+        outs = []
+        for _ in range(4):
+            out = torch.full_like(src, 7.0)
+            ops.transformer_fused(src, 256, out, 256, S, N, wst, fpw, pvec, ne, nd)
+            torch.cuda.synchronize()
+            outs.append(out)
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), "enc %d dec %d: %d elements differ between launches" % (ne, nd, int((outs[0] != o).sum()))
