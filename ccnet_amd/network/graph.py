@@ -475,8 +475,17 @@ class Compiler:
         out = self.new(5 + nc, x.H, x.W, torch.float32)
         wreg, breg = self.folded("reg_preds.%d" % k, "plain")
         wobj, bobj = self.folded("obj_preds.%d" % k, "plain")
-        self.conv_w(torch.cat([wreg, wobj], 0), torch.cat([breg, bobj], 0), [reg_f], 1, 0, "none", out=out.part(0, 5), out_dtype=F32)
         wcls, bcls = self.folded("cls_preds.%d" % k, "plain")
+        if hc % 64 == 0 and os.environ.get("CCNET_SPLIT_PREDS", "0") == "0":
+            # the three prediction convs of a level as ONE launch: a block-diagonal 1x1 over cat[reg_f | cls_f] (two input
+            # segments, no copy).  The zero blocks add exact zeros to the fp32 accumulators, so the logits are unchanged.
+            wp = torch.zeros(5 + nc, 2 * hc, 1, 1, dtype=wreg.dtype)
+            wp[:4, :hc] = wreg
+            wp[4:5, :hc] = wobj
+            wp[5:, hc:] = wcls
+            self.conv_w(wp, torch.cat([breg, bobj, bcls], 0), [reg_f, cls_f], 1, 0, "none", out=out, out_dtype=F32)
+            return out
+        self.conv_w(torch.cat([wreg, wobj], 0), torch.cat([breg, bobj], 0), [reg_f], 1, 0, "none", out=out.part(0, 5), out_dtype=F32)
         self.conv_w(wcls, bcls, [cls_f], 1, 0, "none", out=out.part(5, nc), out_dtype=F32)
         return out
 
