@@ -59,6 +59,9 @@ def lib():
         L.ccnet_decode.argtypes = [C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32),
                                    i32, i32, i32, f32, f32, vp, vp]
         L.ccnet_filter.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp]
+        L.ccnet_filter_workspace_ints.argtypes = [i32, i32]
+        L.ccnet_filter_workspace_ints.restype = sz
+        L.ccnet_filter_ws.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, vp]
         L.ccnet_nms_workspace_bytes.argtypes = [i32, i32]
         L.ccnet_nms_workspace_bytes.restype = sz
         L.ccnet_nms.argtypes = [vp, vp, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp]

@@ -61,16 +61,56 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeP p) {
 // them, so their latencies overlap) and leaves one flag bit per anchor in a register and one count per (iteration, wave) in
 // LDS; one scan turns the counts into output offsets; pass 2 re-reads only the kept rows (L2-hot) and writes them.  The
 // previous form paid a global-load round trip and three barriers per 1024 anchors (23 us for 8400 anchors x 64 images).
-constexpr int F_IT = 32;
-__global__ __launch_bounds__(1024) void filter_kernel(const float* pred, int A, int nc, float conf, float* cand, int* counts) {
+constexpr int F_IT = 32, F_SUPER = F_IT * 1024;
+// keep test of one anchor: obj * max class score >= conf (fp32, the comparisons of pass 2)
+__device__ __forceinline__ bool filter_keep(const float* r, int nc, float conf) {
+    const float obj = r[4];
+    float cc = r[5];
+    for (int c = 1; c < nc; ++c) {
+        const float v = r[5 + c];
+        if (v > cc) cc = v;
+    }
+    return (obj * cc) >= conf;
+}
+// kept anchors per (image, super-chunk): lets filter_kernel run one block per super-chunk on maps with many anchors
+__global__ __launch_bounds__(1024) void filter_count_kernel(const float* pred, int A, int nc, float conf, int nsuper, int* chunk_counts) {
+    __shared__ int tot;
+    const int b = blockIdx.x, sc = blockIdx.y, t = threadIdx.x;
+    const int nch = 5 + nc;
+    const float* pb = pred + (size_t)b * A * nch;
+    if (t == 0) tot = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int a = sc * F_SUPER + t; a < min(A, (sc + 1) * F_SUPER); a += 1024) mine += filter_keep(pb + (size_t)a * nch, nc, conf) ? 1 : 0;
+    const unsigned long long any = __ballot(mine != 0);
+    if (any) {
+        int v = mine;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((t & 63) == 0) atomicAdd(&tot, v);
+    }
+    __syncthreads();
+    if (t == 0) chunk_counts[b * nsuper + sc] = tot;
+}
+// chunk_counts == nullptr: one block per image walks all super-chunks; otherwise block (image, y) does super-chunk y and starts
+// at the sum of the earlier chunks' counts
+__global__ __launch_bounds__(1024) void filter_kernel(const float* pred, int A, int nc, float conf, float* cand, int* counts, int nsuper,
+                                                     const int* chunk_counts) {
     __shared__ int cnt[F_IT * 16];
     __shared__ int base_s;
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nch = 5 + nc;
     const float* pb = pred + (size_t)b * A * nch;
     float* cb = cand + (size_t)b * A * 7;
-    if (t == 0) base_s = 0;
-    for (int s0 = 0; s0 < A; s0 += F_IT * 1024) {
+    const int s_first = chunk_counts ? (int)blockIdx.y * F_SUPER : 0;
+    const int s_end = chunk_counts ? min(A, s_first + F_SUPER) : A;
+    if (t == 0) {
+        int base = 0;
+        if (chunk_counts)
+            for (int y = 0; y < (int)blockIdx.y; ++y) base += chunk_counts[b * nsuper + y];
+        base_s = base;
+    }
+    for (int s0 = s_first; s0 < s_end; s0 += F_IT * 1024) {
         const int iters = min(F_IT, (A - s0 + 1023) / 1024);
         unsigned flags = 0u;
         for (int k = 0; k < iters; ++k) {
@@ -128,7 +168,7 @@ __global__ __launch_bounds__(1024) void filter_kernel(const float* pred, int A, 
         }
         __syncthreads();  // cnt is rewritten by the next super-chunk
     }
-    if (t == 0) counts[b] = base_s;
+    if (t == 0 && (!chunk_counts || (int)blockIdx.y == nsuper - 1)) counts[b] = base_s;
 }
 
 // ---- NMS workspace and per-image tables
@@ -934,17 +974,36 @@ extern "C" int ccnet_decode(const float* const* head_dev, const int64_t* sb, con
         stream, CCNET_OP_DECODE, 0.0, 2.0 * B * (double)A * (5 + nc) * 4.0);
 }
 
-extern "C" int ccnet_filter(const float* pred_dev, int B, int A, int nc, float conf_thres, float* cand_dev, int32_t* counts_dev,
-                            ccnet_stream stream) {
+extern "C" size_t ccnet_filter_workspace_ints(int B, int A) {
+    if (B <= 0 || A <= F_SUPER) return 0;
+    return (size_t)B * ((A + F_SUPER - 1) / F_SUPER);
+}
+
+extern "C" int ccnet_filter_ws(const float* pred_dev, int B, int A, int nc, float conf_thres, float* cand_dev, int32_t* counts_dev,
+                               int32_t* workspace_dev, ccnet_stream stream) {
     CC_REQUIRE(pred_dev && cand_dev && counts_dev, "filter: null pointer");
-    CC_REQUIRE(B > 0 && B <= 65535 && A > 0 && nc > 0, "filter: bad sizes");
+    CC_REQUIRE(B > 0 && B <= 65535 && A > 0 && nc >= 1 && nc <= 1024, "filter: bad sizes (B=%d A=%d nc=%d)", B, A, nc);
+    const int nsuper = (A + F_SUPER - 1) / F_SUPER;
+    CC_REQUIRE(nsuper <= 65535, "filter: too many anchors (%d)", A);
+    int32_t* cc = nsuper > 1 ? workspace_dev : nullptr;  // without a workspace one block per image walks every super-chunk
     return ccnet_submit(
         [=](hipStream_t st, const float*) -> int {
-            hipLaunchKernelGGL(filter_kernel, dim3(B), dim3(1024), 0, st, pred_dev, A, nc, conf_thres, cand_dev, counts_dev);
+            if (cc) {
+                hipLaunchKernelGGL(filter_count_kernel, dim3(B, nsuper), dim3(1024), 0, st, pred_dev, A, nc, conf_thres, nsuper, cc);
+                hipLaunchKernelGGL(filter_kernel, dim3(B, nsuper), dim3(1024), 0, st, pred_dev, A, nc, conf_thres, cand_dev, counts_dev, nsuper, cc);
+            } else {
+                hipLaunchKernelGGL(filter_kernel, dim3(B), dim3(1024), 0, st, pred_dev, A, nc, conf_thres, cand_dev, counts_dev, nsuper,
+                                   (const int*)nullptr);
+            }
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
         stream, CCNET_OP_FILTER, 0.0, (double)B * A * (5 + nc) * 4.0);
+}
+
+extern "C" int ccnet_filter(const float* pred_dev, int B, int A, int nc, float conf_thres, float* cand_dev, int32_t* counts_dev,
+                            ccnet_stream stream) {
+    return ccnet_filter_ws(pred_dev, B, A, nc, conf_thres, cand_dev, counts_dev, nullptr, stream);
 }
 
 extern "C" size_t ccnet_nms_workspace_bytes(int B, int nmax) {

@@ -268,6 +268,11 @@ def decode(heads, nc, in_h, in_w, out):
 
 def filter_candidates(pred, nc, conf, cand, counts):
     B, A, _ = pred.shape
+    nws = int(lib().ccnet_filter_workspace_ints(B, A))
+    if nws:  # many anchors per image: one workgroup per 32768 anchors after a counting pass
+        ws = torch.empty(nws, dtype=torch.int32, device=pred.device)
+        check(lib().ccnet_filter_ws(pred.data_ptr(), B, A, nc, float(np.float32(conf)), cand.data_ptr(), counts.data_ptr(), ws.data_ptr(), stream_ptr()))
+        return
     check(lib().ccnet_filter(pred.data_ptr(), B, A, nc, float(np.float32(conf)), cand.data_ptr(), counts.data_ptr(), stream_ptr()))
 
 

@@ -161,6 +161,12 @@ int ccnet_decode(const float* const* head_dev, const int64_t* sb, const int64_t*
  * cand_dev: fp32 [B][A][7] rows [x1,y1,x2,y2,obj,cls_conf,cls_id]; counts_dev: int32 [B]. */
 int ccnet_filter(const float* pred_dev, int B, int A, int nc, float conf_thres, float* cand_dev, int32_t* counts_dev,
                  ccnet_stream stream);
+/* The same with a small workspace (ccnet_filter_workspace_ints(B, A) int32; 0 for A <= 32768): maps with more anchors than
+ * one workgroup's super-chunk (a 1280x1280 input has 136 000) then run one workgroup per (image, 32768 anchors) after a
+ * counting pass instead of one workgroup per image; results are identical.  workspace_dev may be NULL (= ccnet_filter). */
+size_t ccnet_filter_workspace_ints(int B, int A);
+int ccnet_filter_ws(const float* pred_dev, int B, int A, int nc, float conf_thres, float* cand_dev, int32_t* counts_dev,
+                    int32_t* workspace_dev, ccnet_stream stream);
 /* post_process part 2 (utils/bbox.py:133-158): torchvision.ops.boxes.batched_nms (0.9.0 coordinate trick; third party,
  * see DESIGN.md) + gather + rescale to image pixels.  Above 256 rows per image the work is partitioned by class group
  * (classes whose offset boxes cannot meet), which leaves every bit of the global algorithm's result unchanged.

@@ -781,3 +781,37 @@ def test_transformer_fused_is_run_to_run_identical():
             outs.append(out)
         for o in outs[1:]:
             assert torch.equal(outs[0], o), "enc %d dec %d: %d elements differ between launches" % (ne, nd, int((outs[0] != o).sum()))
+
+
+def test_filter_many_anchors_multi_block_equals_single_block():
+    """ccnet_filter_ws (one workgroup per 32768 anchors after a counting pass, for maps like the 136 000 anchors of a 1280^2
+    input) against ccnet_filter (one workgroup per image): same rows in the same order, same counts; images with no, few, many
+    and all anchors kept, and an anchor count that is not a multiple of anything."""
+    from ccnet_amd import _lib
+    L = _lib.lib()
+    B, A, nc = 5, 70001, 6
+    g = torch.Generator().manual_seed(9)
+    pred = torch.rand(B, A, 5 + nc, generator=g)
+    pred[0, :, 4] = 0.0           # nothing kept
+    pred[1, :, 4] *= 0.4          # few
+    pred[3, :, 4:] = 1.0          # everything kept
+    pred[4, 40000:, 4] = 0.0      # only the first two super-chunks contribute
+    pred = pred.to(DEV).contiguous()
+    res = []
+    for use_ws in (False, True):
+        cand = torch.full((B, A, 7), -1.0, device=DEV)
+        counts = torch.full((B,), -1, dtype=torch.int32, device=DEV)
+        if use_ws:
+            n = int(L.ccnet_filter_workspace_ints(B, A))
+            assert n == B * 3
+            ws = torch.empty(n, dtype=torch.int32, device=DEV)
+            _lib.check(L.ccnet_filter_ws(pred.data_ptr(), B, A, nc, 0.3, cand.data_ptr(), counts.data_ptr(), ws.data_ptr(), _lib.stream_ptr()))
+        else:
+            _lib.check(L.ccnet_filter(pred.data_ptr(), B, A, nc, 0.3, cand.data_ptr(), counts.data_ptr(), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        res.append((cand.cpu(), counts.cpu()))
+    (c0, n0), (c1, n1) = res
+    assert torch.equal(n0, n1) and int(n0[0]) == 0 and int(n0[3]) == A and 0 < int(n0[1]) < int(n0[2])
+    for b in range(B):
+        assert torch.equal(c0[b, :n0[b]], c1[b, :n1[b]]), b
+    assert int(L.ccnet_filter_workspace_ints(64, 8400)) == 0
