@@ -815,3 +815,33 @@ def test_filter_many_anchors_multi_block_equals_single_block():
     for b in range(B):
         assert torch.equal(c0[b, :n0[b]], c1[b, :n1[b]]), b
     assert int(L.ccnet_filter_workspace_ints(64, 8400)) == 0
+
+
+def test_csp_fused_is_run_to_run_identical():
+    """Repeated launches of the fused CSP kernel at a network-sized problem (many tiles per persistent workgroup) must agree bit
+    for bit -- hidden 32 with the weights staged in LDS (a missing barrier after that staging once made this fail), hidden 64
+    with the weights streamed."""
+    import os
+    from ccnet_amd import ops
+    from ccnet_amd._lib import BF16
+    from ccnet_amd.network import graph
+    os.environ["CCNET_FUSED_CSP_ALL"] = "1"
+    try:
+        for h, cin, B, H, W in ((32, 64, 16, 160, 160), (64, 128, 16, 80, 80)):
+            gen = torch.Generator().manual_seed(h)
+            sd = _csp_state("blk", cin, h, gen)
+            comp = graph.Compiler(sd, {}, B, H, W, BF16, torch.device(DEV), "silu")
+            x = graph.T((torch.randn(B, H, W, cin, generator=gen) * 0.8).to(DEV, torch.bfloat16), 0, cin, H, W)
+            with ops.Recorder() as rec:
+                out = comp.csp("blk", [x], 1, True)
+            plan = ops.Plan(rec.handle, comp.keep)
+            ref = None
+            for _ in range(6):
+                out.buf.fill_(3.0)
+                plan.run()
+                torch.cuda.synchronize()
+                cur = out.buf.clone()
+                assert ref is None or torch.equal(ref, cur), "hidden %d: %d elements differ" % (h, int((ref != cur).sum()))
+                ref = cur
+    finally:
+        os.environ.pop("CCNET_FUSED_CSP_ALL", None)
