@@ -1,5 +1,6 @@
 // Shared host/device helpers for libccnet_hip.so (gfx950 only).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -41,10 +42,40 @@ static inline bool cc_slice_vec_ok(const ccnet_slice& s, int dtype) {
            (s.C % g) == 0 && ((uintptr_t)s.ptr % 16) == 0 && s.shift >= 0 && s.shift <= 3;
 }
 
+// CCNET_NO_XCD_REMAP=1 gives the persistent kernels their plain tile order back (tuning / bisecting aid), see cc_tile_walk
+static inline int cc_xcd_remap() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CCNET_NO_XCD_REMAP");
+        v = (e && atoi(e) != 0) ? 0 : 1;
+    }
+    return v;
+}
+
 // ---- device helpers -------------------------------------------------------------------------------------
 #ifdef __HIPCC__
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// Tile walk of a persistent block: tiles first, first + stride, ... below end.  Plain order: block b takes b, b + grid, ...
+// The 8 XCDs have an L2 each and blocks are dealt to them round-robin (blocks b and b + 8 share one; observed, not promised:
+// a speed matter only), so in plain order the tiles in flight on one L2 are 8 apart and every halo row or column that two
+// neighbouring tiles share is fetched through two L2s.  With `xcd` set (and the grid a multiple of 8) the blocks of one
+// label walk a contiguous eighth of the tile range together: neighbours in x and y are in flight on the same L2.
+// The number of rounds does not change: ceil(ceil(n / 8) / (grid / 8)) == ceil(n / grid).
+__device__ __forceinline__ void cc_tile_walk(unsigned ntiles, int xcd, unsigned& first, unsigned& stride, unsigned& end) {
+    const unsigned g = gridDim.x, b = blockIdx.x;
+    if (xcd && (g & 7u) == 0u) {
+        const unsigned per = (ntiles + 7u) >> 3, x = b & 7u;
+        stride = g >> 3;
+        first = x * per + (b >> 3);
+        end = min((x + 1u) * per, ntiles);
+    } else {
+        first = b;
+        stride = g;
+        end = ntiles;
+    }
+}
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float x) {

@@ -32,6 +32,7 @@ struct ConvQ {
     int out_ldc, out_coff;
     int vec_out;
     int flat;  // 1x1 stride-1 unpadded, no upsampled operand: input pixel index == output pixel index
+    int xcd;   // tile order, see cc_tile_walk
 };
 
 template <typename T> struct Frag;

@@ -44,9 +44,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvQ
     static_assert(A_LOADS + B_LOADS + 2 * MT * NT < 64, "vmcnt is a 6-bit counter");
     __shared__ __align__(16) unsigned char smem[NST * BUF_BYTES];
 
-    const unsigned tile0 = blockIdx.x, tstride = gridDim.x;
-    if (tile0 >= p.ntiles) return;
-    const unsigned my_tiles = (p.ntiles - tile0 + tstride - 1) / tstride;
+    unsigned tile0, tstride, tend;
+    cc_tile_walk(p.ntiles, p.xcd, tile0, tstride, tend);
+    if (tile0 >= tend) return;
+    const unsigned my_tiles = (tend - tile0 + tstride - 1) / tstride;
     const unsigned total = my_tiles * (unsigned)p.nk;
 
     const int t = threadIdx.x;
@@ -569,6 +570,7 @@ extern "C" int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream) {
         vec = vec && (r.ldc % rg) == 0 && (r.coff % rg) == 0 && ((uintptr_t)r.ptr % 16) == 0 && (r.ldc % 8) == 0 && (r.coff % 8) == 0;
     }
     p.vec_out = vec ? 1 : 0;
+    p.xcd = cc_xcd_remap();
     p.flat = (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && p.seg[0].shift == 0 && p.seg[1].shift == 0) ? 1 : 0;
     const double flops = 2.0 * (double)M * d->Cout * d->kh * d->kw * ctot;
     const double bytes = ((double)d->B * d->H * d->W * ctot + (double)d->Cout * d->kh * d->kw * ctot) * es +

@@ -49,6 +49,7 @@ struct PatchQ {
     int out_ldc, out_coff;
     int vec_out;
     int mc;  // tile geometry (16 or 8), see PPIX
+    int xcd; // tile order, see cc_tile_walk
 };
 
 // One K step (chunk, tap) of the main loop with the tap as a compile-time constant; expanded nine times in the kernel so
@@ -120,9 +121,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
     unsigned char* const patch0 = smem;
     unsigned char* const bt0 = smem + 2 * PATCH_BYTES;
 
-    const unsigned tile0 = blockIdx.x, tstride = gridDim.x;
-    if (tile0 >= p.ntiles) return;
-    const unsigned my_tiles = (p.ntiles - tile0 + tstride - 1) / tstride;
+    unsigned tile0, tstride, tend;
+    cc_tile_walk(p.ntiles, p.xcd, tile0, tstride, tend);
+    if (tile0 >= tend) return;
+    const unsigned my_tiles = (tend - tile0 + tstride - 1) / tstride;
     const unsigned total_chunks = my_tiles * (unsigned)p.nchunks;
 
     const int t = threadIdx.x, lane = t & 63;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
         const unsigned per_img = (unsigned)(p.tiles_x * p.tiles_y);
         const unsigned b = tile / per_img, rem = tile - b * per_img;
         const int ty = (int)(rem / (unsigned)p.tiles_x), tx = (int)(rem - (unsigned)ty * p.tiles_x);
-        const bool tv = tile < p.ntiles;
+        const bool tv = tile < tend;
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int r = 8 * (wave + 4 * i) + (lane >> 3);
@@ -449,6 +451,7 @@ int ccnet_conv2d_patch_try(const ccnet_conv_desc* d, const double* span, int kpa
     p.Hv = d->Ho; p.Wv = d->Wo; p.Hin = d->H; p.Win = d->W;
     p.Cout = d->Cout;
     p.mc = mc;
+    p.xcd = cc_xcd_remap();
     p.tiles_x = (d->Wo + mc - 1) / mc;
     p.tiles_y = (d->Ho + th - 1) / th;
     p.ntiles = (unsigned)((long long)d->B * p.tiles_x * p.tiles_y);

@@ -43,6 +43,7 @@ struct CspP {
     const float* bias;
     int B, H, W, tiles_x, tiles_y;
     unsigned ntiles;
+    int xcd;  // tile order, see cc_tile_walk
 };
 
 // 16-byte chunk c of row r.  RB = 128: eight chunks per row; RB = 64: four (two rows share a 128-byte line)
@@ -187,8 +188,10 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void csp_fused_kernel(const CspP
     const int nt0 = (wave / WPN) * NTW;  // stage 1: first n-tile of the wave among the 2*H16 of [x_1 | x_2]
     const int mp1 = wave % WPN;          // and its share of that n-tile's m-tiles
     const bool isx1 = nt0 < H16;         // x_1 on the whole patch (12 m-tiles), x_2 on the inner pixels (8)
-    if (blockIdx.x < p.ntiles) xload(blockIdx.x, 0);
-    for (unsigned tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    unsigned tile0, tstride, tend;
+    cc_tile_walk(p.ntiles, p.xcd, tile0, tstride, tend);
+    if (tile0 < tend) xload(tile0, 0);
+    for (unsigned tile = tile0; tile < tend; tile += tstride) {
         const int tx = (int)(tile % (unsigned)p.tiles_x);
         const int rest = (int)(tile / (unsigned)p.tiles_x);
         const int ty = rest % p.tiles_y, b = rest / p.tiles_y;
@@ -331,8 +334,8 @@ __global__ __launch_bounds__(NWV * 64, NWV / 2) void csp_fused_kernel(const CspP
 
         // ---- stage 4: out = SiLU(W3 [x_1' | x_2] + b) -> global; the next tile's first patch chunk is fetched underneath
         {
-            const unsigned next = tile + gridDim.x;
-            if (next < p.ntiles) xload(next, 0);
+            const unsigned next = tile + tstride;
+            if (next < tend) xload(next, 0);
             f32x4 acc[MT4][NT4];
 #pragma unroll
             for (int m = 0; m < MT4; ++m)
@@ -424,6 +427,7 @@ extern "C" int ccnet_csp_fused(const ccnet_slice* in, int nseg, int B, int H, in
     p.B = B; p.H = H; p.W = W;
     p.tiles_x = W / TW; p.tiles_y = H / TH;
     p.ntiles = (unsigned)((long long)B * p.tiles_x * p.tiles_y);
+    p.xcd = cc_xcd_remap();
     const double px = (double)B * H * W;
     const double flops = 2.0 * px * ((double)cin * 2 * hidden + (double)hidden * hidden + 9.0 * hidden * hidden + 4.0 * hidden * hidden);
     double bytes = px * 2.0 * hidden * 2.0 + 2.0 * (double)ccnet_csp_fused_weight_elems(cin, hidden);

@@ -28,6 +28,7 @@ struct StemP {
     int out_ldc, out_coff;
     int tiles_x, tiles_y;
     unsigned ntiles;
+    int xcd;  // tile order, see cc_tile_walk
 };
 
 template <typename T, typename OutT, int NT>
@@ -96,15 +97,16 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemP p, const float* x
             }
     };
 
-    unsigned tile = blockIdx.x;
-    if (tile >= p.ntiles) return;
+    unsigned tile, tstride, tend;
+    cc_tile_walk(p.ntiles, p.xcd, tile, tstride, tend);
+    if (tile >= tend) return;
     fetch(tile);
-    for (int it = 0; tile < p.ntiles; tile += gridDim.x, ++it) {
+    for (int it = 0; tile < tend; tile += tstride, ++it) {
         const int buf = it & 1;
         stash(buf);
         __syncthreads();  // also orders the weight fill; the other buffer was last read before the previous barrier
-        const unsigned next = tile + gridDim.x;
-        if (next < p.ntiles) fetch(next);  // in flight during the MFMAs
+        const unsigned next = tile + tstride;
+        if (next < tend) fetch(next);  // in flight during the MFMAs
 
         const T* pt = patch[buf];
         // wave w owns output rows 2w, 2w+1; M tile mt -> (row 2w + mt/2, cols (mt&1)*16 ..)
@@ -257,6 +259,7 @@ extern "C" int ccnet_stem_conv(const float* x_dev, int B, int H, int W, const fl
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;
     p.ntiles = (unsigned)((long long)B * p.tiles_x * p.tiles_y);
+    p.xcd = cc_xcd_remap();
     return ccnet_submit(
         [p, out_dtype](hipStream_t st, const float* xo) -> int {
             const float* x = xo ? xo : p.x;
