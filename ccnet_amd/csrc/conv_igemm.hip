@@ -25,6 +25,7 @@
 
 int ccnet_conv2d_generic(const ccnet_conv_desc* d, ccnet_stream stream);  // conv_generic.hip
 int ccnet_conv2d_patch_try(const ccnet_conv_desc* d, const double* span, int kpad, ccnet_launch_fn* launch);  // conv_patch.hip
+int ccnet_conv2d_stream_try(const ccnet_conv_desc* d, int kpad, ccnet_launch_fn* launch);                      // conv_stream.hip
 
 namespace {
 
@@ -575,6 +576,10 @@ extern "C" int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream) {
     const double flops = 2.0 * (double)M * d->Cout * d->kh * d->kw * ctot;
     const double bytes = ((double)d->B * d->H * d->W * ctot + (double)d->Cout * d->kh * d->kw * ctot) * es +
                          (double)M * d->Cout * (cc_esize(d->out_dtype) + (d->residual.ptr ? es : 0));
+    {   // thin 1x1 layers (K, N <= 256): weights resident in LDS, pixels streamed
+        ccnet_launch_fn stream_fn;
+        if (o.ptr && o.shift == 0 && ccnet_conv2d_stream_try(d, kpad, &stream_fn)) return ccnet_submit(stream_fn, stream, CCNET_OP_CONV, flops, bytes);
+    }
     {   // 3x3 s1 p1 and SpaceToDepth (6x6 s2 p2) layers on 16-aligned widths: LDS halo-patch kernel
         ccnet_launch_fn patch_fn;
         if (ccnet_conv2d_patch_try(d, span, kpad, &patch_fn)) return ccnet_submit(patch_fn, stream, CCNET_OP_CONV, flops, bytes);

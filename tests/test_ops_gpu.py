@@ -128,6 +128,59 @@ def test_conv2d_two_segments_with_upsample(code):
         assert rel(from_nhwc(out, 0, 48), ref) < tol(code)
 
 
+@pytest.mark.parametrize("B,H,W,cins,cout,act", [
+    (21, 57, 55, (128,), 128, "silu"),       # M = 65835: the last block holds 11 pixels
+    (64, 40, 40, (256,), 256, "silu"),       # two passes, 128 KB of weights in LDS (dark4 conv3)
+    (17, 64, 61, (128, 128), 192, "none"),   # concatenated input, second pass of four tiles, no activation
+    (9, 96, 80, (64, 64), 64, "silu"),       # one pass of four tiles
+    (16, 80, 80, (32, 224), 128, "silu"),    # uneven segments
+    (2, 16, 20, (128,), 128, "silu"),        # too few pixels for this kernel: the implicit-GEMM kernel takes it
+])
+def test_conv1x1_stream_kernel_matches_torch(B, H, W, cins, cout, act):
+    """The thin 1x1 layers (BaseConv k1 of CSPLayer / the neck, network/model_block.py:31-60) on the LDS-resident-weight
+    streaming kernel (conv_stream.hip): channel slices with offsets, concatenated inputs, ragged pixel counts."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(23)
+    K = sum(cins)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in cins]
+    w = torch.randn(cout, K, 1, 1, generator=g) / math.sqrt(K)
+    bias = torch.randn(cout, generator=g) * 0.1
+    pc = ops.PackedConv(w, bias, 1, DEV)
+    ts = [to_nhwc(x, 1, ldc=x.shape[1] + 16 * i, coff=8 * i) for i, x in enumerate(xs)]
+    out = torch.full((B, H, W, cout + 24), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.conv2d([ops.sl(t, 8 * i, c) for i, (t, c) in enumerate(zip(ts, cins))], pc, B, H, W, 1, 0, ops.sl(out, 8, cout), act)
+    torch.cuda.synchronize()
+    ref = F.conv2d(torch.cat([q(x, 1) for x in xs], 1), q(w, 1), bias)
+    if act == "silu":
+        ref = F.silu(ref)
+    assert rel(from_nhwc(out, 8, cout), ref) < tol(1)
+    # channels around the slice are untouched
+    assert bool((out[..., :8] == 7.0).all()) and bool((out[..., 8 + cout:] == 7.0).all())
+
+
+@pytest.mark.parametrize("cins,cout", [((128,), 128), ((128, 128), 256)])
+def test_conv1x1_stream_equals_implicit_gemm_bitwise(cins, cout):
+    """Which kernel a thin 1x1 layer gets depends on its pixel count (conv_stream.hip takes 65536 and more), so the two must
+    agree bit for bit: a 16-image batch (streaming kernel) against its two halves (implicit-GEMM kernel)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(29)
+    B, H, W = 16, 64, 64
+    K = sum(cins)
+    ts = [(torch.randn(B, H, W, c, generator=g) * 2).to(torch.bfloat16).to(DEV) for c in cins]
+    w = torch.randn(cout, K, 1, 1, generator=g) / math.sqrt(K)
+    pc = ops.PackedConv(w, torch.randn(cout, generator=g), 1, DEV)
+    whole = torch.zeros(B, H, W, cout, dtype=torch.bfloat16, device=DEV)
+    ops.conv2d([ops.sl(t) for t in ts], pc, B, H, W, 1, 0, ops.sl(whole), "silu")
+    halves = torch.zeros_like(whole)
+    for h in range(2):
+        sub = [t[h * 8:(h + 1) * 8].contiguous() for t in ts]
+        out = torch.zeros(8, H, W, cout, dtype=torch.bfloat16, device=DEV)
+        ops.conv2d([ops.sl(t) for t in sub], pc, 8, H, W, 1, 0, ops.sl(out), "silu")
+        halves[h * 8:(h + 1) * 8] = out
+    torch.cuda.synchronize()
+    assert torch.equal(whole.view(torch.int16), halves.view(torch.int16))
+
+
 @pytest.mark.parametrize("code", [0, 1])
 def test_conv3x3_two_segments_patch_kernel(code):
     """3x3 over torch.cat([a, b], 1) at a 16-aligned width (MobileViT conv4, network/model_block.py:296-297): the halo-patch
