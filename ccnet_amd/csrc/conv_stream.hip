@@ -27,6 +27,9 @@ struct StreamQ {
     const unsigned char* in1;
     unsigned ldc0B, ldc1B;  // pixel strides in bytes
     int KS0;                // k-steps (32 channels) that come from segment 0
+    int shift0, shift1;     // nearest-neighbour upsampling of a segment (nn.Upsample before the torch.cat): pixel (y, x) reads (y >> s, x >> s)
+    int H, W;               // output = unshifted input size
+    unsigned magicW, shiftW, magicH, shiftH;
     unsigned M, nblocks;
     int Cout;               // multiple of 64
     const unsigned char* weight;  // packed [Cout_pad][Kpad] bf16
@@ -76,9 +79,17 @@ __global__ __launch_bounds__(SW * 64, SW / 4) void conv_stream_kernel(const Stre
     if (blk >= p.nblocks) return;
 
     // the lane's 16 bytes of pixel tile tt, k-step ks of block b (rows beyond M read the last pixel; they are not stored)
+    const bool shifted = (p.shift0 | p.shift1) != 0;  // uniform
     auto xload = [&](unsigned b, int tt, int ks) -> u32x4 {
         const unsigned m = min(b * PXB + tt * 16 + fr, p.M - 1u);
-        const unsigned char* src = ks < p.KS0 ? p.in0 + (size_t)m * p.ldc0B + ks * 64 : p.in1 + (size_t)m * p.ldc1B + (ks - p.KS0) * 64;
+        unsigned m0 = m, m1 = m;
+        if (shifted) {
+            const unsigned q1 = fastdiv(m, p.magicW, p.shiftW), xx = m - q1 * (unsigned)p.W;
+            const unsigned bi = fastdiv(q1, p.magicH, p.shiftH), yy = q1 - bi * (unsigned)p.H;
+            m0 = (bi * (unsigned)(p.H >> p.shift0) + (yy >> p.shift0)) * (unsigned)(p.W >> p.shift0) + (xx >> p.shift0);
+            m1 = (bi * (unsigned)(p.H >> p.shift1) + (yy >> p.shift1)) * (unsigned)(p.W >> p.shift1) + (xx >> p.shift1);
+        }
+        const unsigned char* src = ks < p.KS0 ? p.in0 + (size_t)m0 * p.ldc0B + ks * 64 : p.in1 + (size_t)m1 * p.ldc1B + (ks - p.KS0) * 64;
         return *(const u32x4*)(src + fq * 16);
     };
     const int npass = (NT + NTP - 1) / NTP;
@@ -233,7 +244,7 @@ int ccnet_conv2d_stream_try(const ccnet_conv_desc* d, int kpad, ccnet_launch_fn*
     int ctot = 0;
     for (int s = 0; s < d->nseg; ++s) {
         const ccnet_slice& sl = d->in[s];
-        if (sl.shift != 0 || (sl.C % 32) != 0 || (sl.ldc % 8) != 0 || (sl.coff % 8) != 0 || ((uintptr_t)sl.ptr % 16) != 0) return 0;
+        if (sl.shift < 0 || sl.shift > 3 || (d->H % (1 << sl.shift)) != 0 || (d->W % (1 << sl.shift)) != 0 || (sl.C % 32) != 0 || (sl.ldc % 8) != 0 || (sl.coff % 8) != 0 || ((uintptr_t)sl.ptr % 16) != 0) return 0;
         ctot += sl.C;
     }
     if (ctot != 128 && ctot != 256) return 0;  // K = 64 (one k-step pair) measures no better here than in conv_igemm
@@ -256,6 +267,19 @@ int ccnet_conv2d_stream_try(const ccnet_conv_desc* d, int kpad, ccnet_launch_fn*
         p.ldc1B = p.ldc0B;
     }
     p.M = (unsigned)M;
+    p.shift0 = d->in[0].shift;
+    p.shift1 = d->nseg == 2 ? d->in[1].shift : d->in[0].shift;
+    p.H = d->H; p.W = d->W;
+    {
+        auto magic = [](unsigned dv, unsigned* mg, unsigned* sh) {
+            unsigned s = 0;
+            while ((1ull << s) < dv) ++s;
+            *sh = s;
+            *mg = (unsigned)((((1ull << s) - dv) << 32) / dv + 1);
+        };
+        magic((unsigned)d->W, &p.magicW, &p.shiftW);
+        magic((unsigned)d->H, &p.magicH, &p.shiftH);
+    }
     p.Cout = d->Cout;
     p.weight = (const unsigned char*)d->weight;
     p.Kpad = kpad;

@@ -158,27 +158,36 @@ def test_conv1x1_stream_kernel_matches_torch(B, H, W, cins, cout, act):
     assert bool((out[..., :8] == 7.0).all()) and bool((out[..., 8 + cout:] == 7.0).all())
 
 
-@pytest.mark.parametrize("cins,cout", [((128,), 128), ((128, 128), 256)])
-def test_conv1x1_stream_equals_implicit_gemm_bitwise(cins, cout):
+@pytest.mark.parametrize("cins,cout,up", [((128,), 128, 0), ((128, 128), 256, 0), ((128, 128), 128, 1)])
+def test_conv1x1_stream_equals_implicit_gemm_bitwise(cins, cout, up):
     """Which kernel a thin 1x1 layer gets depends on its pixel count (conv_stream.hip takes 65536 and more), so the two must
-    agree bit for bit: a 16-image batch (streaming kernel) against its two halves (implicit-GEMM kernel)."""
+    agree bit for bit: a 16-image batch (streaming kernel) against its two halves (implicit-GEMM kernel).  up = 1: the first
+    input is a half-resolution map read through nearest upsampling (the neck's torch.cat([upsample(a), b]), network/net.py:208-213);
+    that case is also checked against torch."""
     ops = _ops()
     g = torch.Generator().manual_seed(29)
     B, H, W = 16, 64, 64
     K = sum(cins)
-    ts = [(torch.randn(B, H, W, c, generator=g) * 2).to(torch.bfloat16).to(DEV) for c in cins]
+    shifts = [up] + [0] * (len(cins) - 1)
+    ts = [(torch.randn(B, H >> sh, W >> sh, c, generator=g) * 2).to(torch.bfloat16).to(DEV) for c, sh in zip(cins, shifts)]
     w = torch.randn(cout, K, 1, 1, generator=g) / math.sqrt(K)
-    pc = ops.PackedConv(w, torch.randn(cout, generator=g), 1, DEV)
+    bias = torch.randn(cout, generator=g)
+    pc = ops.PackedConv(w, bias, 1, DEV)
     whole = torch.zeros(B, H, W, cout, dtype=torch.bfloat16, device=DEV)
-    ops.conv2d([ops.sl(t) for t in ts], pc, B, H, W, 1, 0, ops.sl(whole), "silu")
+    ops.conv2d([ops.sl(t, 0, c, shift=sh) for t, c, sh in zip(ts, cins, shifts)], pc, B, H, W, 1, 0, ops.sl(whole), "silu")
     halves = torch.zeros_like(whole)
     for h in range(2):
         sub = [t[h * 8:(h + 1) * 8].contiguous() for t in ts]
         out = torch.zeros(8, H, W, cout, dtype=torch.bfloat16, device=DEV)
-        ops.conv2d([ops.sl(t) for t in sub], pc, 8, H, W, 1, 0, ops.sl(out), "silu")
+        ops.conv2d([ops.sl(t, 0, c, shift=sh) for t, c, sh in zip(sub, cins, shifts)], pc, 8, H, W, 1, 0, ops.sl(out), "silu")
         halves[h * 8:(h + 1) * 8] = out
     torch.cuda.synchronize()
     assert torch.equal(whole.view(torch.int16), halves.view(torch.int16))
+    if up:
+        nchw = [t.float().cpu().permute(0, 3, 1, 2) for t in ts]
+        cat = torch.cat([F.interpolate(nchw[0], scale_factor=2, mode="nearest")] + nchw[1:], 1)
+        ref = F.silu(F.conv2d(cat, q(w, 1), bias))
+        assert rel(from_nhwc(whole, 0, cout), ref) < tol(1)
 
 
 @pytest.mark.parametrize("code", [0, 1])
