@@ -17,6 +17,12 @@
 //    pixel (2y+dy, 2x+dx), channel c (model_block.py:169-173).  A 64-channel chunk is one (dy,dx) (C >= 64) or the pair
 //    dx = 0,1 of one dy (C = 32); its weights are contiguous in the 6x6 packing, so the same packed tensor is used.
 //  * Epilogue, weight tiles, MFMA operand order: as conv_igemm (registers only, weights are the "A" operand).
+//  * Linear geometry (LIN, output maps narrower than 30 pixels whose width is not a multiple of 8 -- the 20 x 20 maps, plain
+//    3x3 and SpaceToDepth layers alike): the batch is
+//    laid out as ONE zero-padded image of width Wp = W + 2 with a zero row between consecutive images; a tile is 128
+//    consecutive positions q = Yp * Wp + Xp of that padded space (pad positions are computed and thrown away: 13 % at 20 x 20),
+//    its patch the 128 + 2 Wp + 2 positions from q0 - Wp - 1 on, and tap (ky, kx) is the same LDS image read ky * Wp + kx rows
+//    further down.  LDS row r keeps 16-B chunk c at slot c ^ ((r >> 1) & 7) (conv_igemm's swizzle; 16-row steps leave it alone).
 #include <stdlib.h>
 #include <type_traits>
 #include "conv_common.h"
@@ -50,6 +56,8 @@ struct PatchQ {
     int vec_out;
     int mc;  // tile geometry (16 or 8), see PPIX
     int xcd; // tile order, see cc_tile_walk
+    int Wp, Hp;  // linear geometry: padded width W + 2, padded rows per image H + 1
+    int B;
 };
 
 // One K step (chunk, tap) of the main loop with the tap as a compile-time constant; expanded nine times in the kernel so
@@ -76,12 +84,21 @@ struct PatchQ {
             { \
                 const unsigned char* Bs = bt0 + bpar * B_BYTES; \
                 u32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT]; \
+                int pa0, pa1; \
+                if constexpr (LIN) { \
+                    const int r0 = lin_row + ky * lin_wp + kx, sw = (r0 >> 1) & 7; \
+                    pa0 = r0 * BKB + ((fq ^ sw) << 4); \
+                    pa1 = r0 * BKB + (((4 + fq) ^ sw) << 4); \
+                } else { \
+                    pa0 = abase[kx][0] + ky * PW * BKB; \
+                    pa1 = abase[kx][1] + ky * PW * BKB; \
+                } \
 _Pragma("unroll") \
-                for (int i = 0; i < MT; ++i) fa0[i] = *(const u32x4*)(pt + abase[kx][0] + ((i * MR + ky) * PW) * BKB); \
+                for (int i = 0; i < MT; ++i) fa0[i] = *(const u32x4*)(pt + pa0 + i * PSTEP); \
 _Pragma("unroll") \
                 for (int j = 0; j < NT; ++j) fb0[j] = *(const u32x4*)(Bs + bbase[j][0]); \
 _Pragma("unroll") \
-                for (int i = 0; i < MT; ++i) fa1[i] = *(const u32x4*)(pt + abase[kx][1] + ((i * MR + ky) * PW) * BKB); \
+                for (int i = 0; i < MT; ++i) fa1[i] = *(const u32x4*)(pt + pa1 + i * PSTEP); \
 _Pragma("unroll") \
                 for (int j = 0; j < NT; ++j) fb1[j] = *(const u32x4*)(Bs + bbase[j][1]); \
                 __builtin_amdgcn_sched_barrier(0); \
@@ -106,10 +123,11 @@ _Pragma("unroll") \
             asm volatile("" ::: "memory"); \
     }
 
-template <typename T, typename OutT, int BN, int MC, int ACT, bool S2D>
+template <typename T, typename OutT, int BN, int MC, int ACT, bool S2D, bool LIN = false>
 __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
     constexpr int MR = 16 / MC, TH = 8 * MR, TW = MC, PW = MC + 2;
     static_assert((TH + 2) * PW == PPIX && (PW % 2) == 0, "patch geometry");
+    constexpr int PSTEP = LIN ? 16 * BKB : MR * PW * BKB;  // LDS bytes between a wave's m-tiles
     constexpr int ES = (int)sizeof(T);
     constexpr int EPC = 16 / ES;
     constexpr int BK = BKB / ES;  // channels per chunk
@@ -150,7 +168,34 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
     // pixel's channel window, for the tile being prefetched (recomputed per tile: a few divisions by constants)
     int pix[PIECES];
     unsigned pr_c[PIECES];
+    // linear geometry: padded position -> pixel index (-1 for pad positions) of the output, or of the stored input tensor
+    // (SpaceToDepth: the top-left pixel of the 2x2 group, plus dx when a chunk holds both columns)
+    auto lin_pixel = [&](int q, bool src, int dx) -> int {
+        if (q < 0) return -1;
+        const int yp = q / p.Wp, xp = q - yp * p.Wp;
+        const int b = yp / p.Hp, yy = yp - b * p.Hp;
+        const bool real = b < p.B && yy >= 1 && xp >= 1 && xp <= p.Wv;
+        if (!real) return -1;
+        if (S2D && src) return (b * p.Hin + 2 * (yy - 1)) * p.Win + 2 * (xp - 1) + dx;
+        return (b * p.Hv + yy - 1) * p.Wv + xp - 1;
+    };
+    const int lin_wp = __builtin_amdgcn_readfirstlane(p.Wp);
+    const int lin_row = wm * 64 + fr;  // LDS row of the lane's pixel in m-tile 0 under tap (0, 0)
     auto setup_tile = [&](unsigned tile) {
+        if constexpr (LIN) {
+            const bool tv = tile < tend;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int r = 8 * (wave + 4 * i) + (lane >> 3);
+                const int lc = (lane & 7) ^ ((r >> 1) & 7);
+                int ch = lc * EPC, dx = 0;
+                if (S2D && p.Creal < BK) { dx = ch >= p.Creal ? 1 : 0; ch -= dx * p.Creal; }
+                pr_c[i] = (unsigned)ch * ES;
+                const int px = (tv && r < 128 + 2 * p.Wp + 2) ? lin_pixel((int)tile * 128 - p.Wp - 1 + r, true, dx) : -1;
+                pix[i] = px;
+            }
+            return;
+        }
         const unsigned per_img = (unsigned)(p.tiles_x * p.tiles_y);
         const unsigned b = tile / per_img, rem = tile - b * per_img;
         const int ty = (int)(rem / (unsigned)p.tiles_x), tx = (int)(rem - (unsigned)ty * p.tiles_x);
@@ -258,6 +303,47 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
     };
     // returns true when exactly S store instructions per lane were issued (and no loads)
     auto epilogue = [&](unsigned tile) -> bool {
+        if constexpr (LIN) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = lin_pixel((int)tile * 128 + wm * 64 + i * 16 + fr, false, 0);
+                if (m >= 0) {
+                    unsigned char* orow = p.out_ptr + ((size_t)m * p.out_ldc + p.out_coff) * sizeof(OutT);
+                    const unsigned char* rrow = p.res_ptr ? p.res_ptr + ((size_t)m * p.res_ldc + p.res_coff) * ES : nullptr;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int n = nbase + j * 16;
+                        if (n >= p.Cout) continue;
+                        float v[4];
+                        finish4(i, j, v);
+                        if (p.vec_out && n + 4 <= p.Cout) {
+                            if (rrow) {
+                                if constexpr (ES == 2) {
+                                    const uint2 rv = *(const uint2*)(rrow + (size_t)n * 2);
+                                    v[0] += bf16_bits_to_f32(rv.x & 0xFFFFu); v[1] += bf16_bits_to_f32(rv.x >> 16);
+                                    v[2] += bf16_bits_to_f32(rv.y & 0xFFFFu); v[3] += bf16_bits_to_f32(rv.y >> 16);
+                                } else {
+                                    const float4 rv = *(const float4*)(rrow + (size_t)n * 4);
+                                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                                }
+                            }
+                            store4(orow + (size_t)n * sizeof(OutT), v);
+                        } else {
+                            for (int r = 0; r < 4 && n + r < p.Cout; ++r) {
+                                float x = v[r];
+                                if (rrow) x += load1<T>((const T*)rrow + n + r);
+                                store1<OutT>((OutT*)orow + n + r, x);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            return false;
+        }
         const unsigned per_img = (unsigned)(p.tiles_x * p.tiles_y);
         const unsigned b = tile / per_img, rem = tile - b * per_img;
         const int ty = (int)(rem / (unsigned)p.tiles_x), tx = (int)(rem - (unsigned)ty * p.tiles_x);
@@ -366,9 +452,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
     if (pending) epilogue(pend_tile);
 }
 
-template <typename T, typename OutT, int BN, int MC, int ACT, bool S2D>
+template <typename T, typename OutT, int BN, int MC, int ACT, bool S2D, bool LIN = false>
 int launch_patch_s2d(const PatchQ& p, hipStream_t st) {
-    auto kernel = conv_patch_kernel<T, OutT, BN, MC, ACT, S2D>;
+    auto kernel = conv_patch_kernel<T, OutT, BN, MC, ACT, S2D, LIN>;
     constexpr int LDS = 2 * PATCH_BYTES + 2 * BN * BKB;
     static int cached[16] = {0};
     int dev = 0;
@@ -402,7 +488,25 @@ int launch_patch_mc(const PatchQ& p, hipStream_t st) {
 }
 template <typename T, typename OutT, int BN>
 int launch_patch_bn(const PatchQ& p, hipStream_t st) {
+    if (p.Wp) {  // linear geometry
+        if (p.s2d) {
+            if (p.act == CCNET_ACT_SILU) return launch_patch_s2d<T, OutT, BN, 16, CCNET_ACT_SILU, true, true>(p, st);
+            return launch_patch_s2d<T, OutT, BN, 16, ACT_RUNTIME, true, true>(p, st);
+        }
+        if (p.act == CCNET_ACT_SILU) return launch_patch_s2d<T, OutT, BN, 16, CCNET_ACT_SILU, false, true>(p, st);
+        if (p.act == CCNET_ACT_NONE) return launch_patch_s2d<T, OutT, BN, 16, CCNET_ACT_NONE, false, true>(p, st);
+        return launch_patch_s2d<T, OutT, BN, 16, ACT_RUNTIME, false, true>(p, st);
+    }
     return p.mc == 16 ? launch_patch_mc<T, OutT, BN, 16>(p, st) : launch_patch_mc<T, OutT, BN, 8>(p, st);
+}
+
+bool lin_enabled() {  // CCNET_NO_LINEAR_PATCH=1: maps whose width is no multiple of 8 stay on conv_igemm
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CCNET_NO_LINEAR_PATCH");
+        v = (e && atoi(e) != 0) ? 0 : 1;
+    }
+    return v == 1;
 }
 
 bool patch_enabled() {  // CCNET_NO_PATCH_CONV=1 sends every conv to conv_igemm (tuning / bisecting aid)
@@ -424,7 +528,10 @@ int ccnet_conv2d_patch_try(const ccnet_conv_desc* d, const double* span, int kpa
     const bool plain = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1;
     const bool s2d = d->kh == 6 && d->kw == 6 && d->stride == 2 && d->pad == 2 && d->nseg == 1 && (d->H % 2) == 0 && (d->W % 2) == 0;
     if (!plain && !s2d) return 0;
-    if (d->Cout < 64 || (d->Wo % 8) != 0) return 0;
+    if (d->Cout < 64) return 0;
+    // widths that are no multiple of 8: the linear geometry, for narrow maps and the bf16 network path only
+    const bool lin = (d->Wo % 8) != 0;
+    if (lin && !(d->Wo <= 29 && d->dtype == CCNET_BF16 && d->out_dtype == CCNET_BF16 && lin_enabled())) return 0;
     const int mc = (d->Wo % 16) == 0 ? 16 : 8, th = 8 * (16 / mc);
     int ctot = 0;
     for (int s = 0; s < d->nseg; ++s) {
@@ -455,6 +562,14 @@ int ccnet_conv2d_patch_try(const ccnet_conv_desc* d, const double* span, int kpa
     p.tiles_x = (d->Wo + mc - 1) / mc;
     p.tiles_y = (d->Ho + th - 1) / th;
     p.ntiles = (unsigned)((long long)d->B * p.tiles_x * p.tiles_y);
+    p.B = d->B;
+    if (lin) {
+        p.Wp = d->Wo + 2;
+        p.Hp = d->Ho + 1;
+        const long long q = ((long long)d->B * p.Hp + 1) * p.Wp;
+        if (q >= (1ll << 30)) return 0;
+        p.ntiles = (unsigned)((q + 127) / 128);
+    }
     p.weight = (const unsigned char*)d->weight;
     p.Kpad = kpad;
     p.nchunks = p.Ctot / bk;

@@ -190,6 +190,60 @@ def test_conv1x1_stream_equals_implicit_gemm_bitwise(cins, cout, up):
         assert rel(from_nhwc(whole, 0, cout), ref) < tol(1)
 
 
+@pytest.mark.parametrize("B,H,W,cins,cout,act,res", [
+    (64, 20, 20, (512,), 512, "silu", False),     # dark5 / MobileViT size
+    (5, 20, 20, (128,), 128, "silu", True),       # bottleneck with shortcut
+    (3, 13, 27, (64, 128), 96, "silu", False),    # H != W, concatenated input, Cout no multiple of the tile
+    (1, 5, 5, (64,), 64, "none", False),          # one image smaller than a tile
+    (7, 10, 10, (256,), 192, "silu", True),
+])
+def test_conv3x3_linear_patch_geometry(B, H, W, cins, cout, act, res):
+    """3x3 stride-1 layers on maps whose width is no multiple of 8 (the 20 x 20 level: Bottleneck / MobileViT convs,
+    network/model_block.py:193-218, 290-297) on the halo-patch kernel's linear geometry: images side by side in one zero-padded
+    space, tiles that straddle image boundaries, pad positions never stored."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    K = sum(cins)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in cins]
+    w = torch.randn(cout, K, 3, 3, generator=g) / math.sqrt(K * 9)
+    bias = torch.randn(cout, generator=g) * 0.1
+    pc = ops.PackedConv(w, bias, 1, DEV)
+    ts = [to_nhwc(x, 1, ldc=x.shape[1] + 16 * i, coff=8 * i) for i, x in enumerate(xs)]
+    r = torch.randn(B, cout, H, W, generator=g)
+    tr = to_nhwc(r, 1)
+    out = torch.full((B, H, W, cout + 8), 3.0, dtype=torch.bfloat16, device=DEV)
+    ops.conv2d([ops.sl(t, 8 * i, c) for i, (t, c) in enumerate(zip(ts, cins))], pc, B, H, W, 1, 1, ops.sl(out, 0, cout), act,
+               ops.sl(tr) if res else None)
+    torch.cuda.synchronize()
+    ref = F.conv2d(torch.cat([q(x, 1) for x in xs], 1), q(w, 1), bias, 1, 1)
+    if act == "silu":
+        ref = F.silu(ref)
+    if res:
+        ref = ref + q(r, 1)
+    assert rel(from_nhwc(out, 0, cout), ref) < tol(1)
+    assert bool((out[..., cout:] == 3.0).all())
+
+
+@pytest.mark.parametrize("B,C,H,W,cout", [(3, 64, 40, 40, 128), (64, 256, 40, 40, 256), (2, 32, 24, 56, 64), (5, 128, 26, 18, 96)])
+def test_s2d_conv_linear_patch_geometry(B, C, H, W, cout):
+    """SpaceToDepth + BaseConv k3 in its 6x6 stride-2 pad-2 form (network/model_block.py:166-175) with an output map whose
+    width is no multiple of 8 (dark5 and the last bottom-up conv write 20 x 20): linear geometry of the halo-patch kernel,
+    64-channel chunks that are one (dy, dx) phase (C >= 64) or a dx pair (C = 32)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(37)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(cout, C, 6, 6, generator=g) / math.sqrt(C * 36)
+    bias = torch.randn(cout, generator=g) * 0.1
+    pc = ops.PackedConv(w, bias, 1, DEV)
+    tx = to_nhwc(x, 1)
+    Ho, Wo = H // 2, W // 2
+    out = torch.zeros(B, Ho, Wo, cout, dtype=torch.bfloat16, device=DEV)
+    ops.conv2d([ops.sl(tx)], pc, B, H, W, 2, 2, ops.sl(out), "silu")
+    torch.cuda.synchronize()
+    ref = F.silu(F.conv2d(q(x, 1), q(w, 1), bias, 2, 2))
+    assert rel(from_nhwc(out, 0, cout), ref) < tol(1)
+
+
 @pytest.mark.parametrize("code", [0, 1])
 def test_conv3x3_two_segments_patch_kernel(code):
     """3x3 over torch.cat([a, b], 1) at a 16-aligned width (MobileViT conv4, network/model_block.py:296-297): the halo-patch
