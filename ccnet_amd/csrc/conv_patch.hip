@@ -488,7 +488,9 @@ int launch_patch_mc(const PatchQ& p, hipStream_t st) {
 }
 template <typename T, typename OutT, int BN>
 int launch_patch_bn(const PatchQ& p, hipStream_t st) {
-    if (p.Wp) {  // linear geometry
+    // linear geometry: only built for the bf16 network path (ccnet_conv2d_patch_try sets Wp for nothing else)
+    if constexpr (std::is_same<T, __bf16>::value && std::is_same<OutT, __bf16>::value)
+    if (p.Wp) {
         if (p.s2d) {
             if (p.act == CCNET_ACT_SILU) return launch_patch_s2d<T, OutT, BN, 16, CCNET_ACT_SILU, true, true>(p, st);
             return launch_patch_s2d<T, OutT, BN, 16, ACT_RUNTIME, true, true>(p, st);
