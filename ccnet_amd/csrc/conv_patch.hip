@@ -60,38 +60,20 @@ struct PatchQ {
     int B;
 };
 
-// One K step (chunk, tap) of the main loop with the tap as a compile-time constant; expanded nine times in the kernel so
-// that every LDS fragment address is a per-lane constant plus an immediate (a lambda here kept the accumulators in memory).
-#define PATCH_STEP(TAP)                                                                                                 \
-    {                                                                                                               \
-        constexpr int tap = TAP;                                                                                    \
-            constexpr int ky = tap / 3, kx = tap - ky * 3; \
-            const int bpar = (cpar ^ tap) & 1; \
-            int after = 0; \
-            if (tap < 8) b_tile(bpar ^ 1, b_koff(kb_cur, tap + 1)); \
-            else if (next_chunk) b_tile(bpar ^ 1, b_koff(kb_next, 0)); \
-            if (tap < PIECES && next_chunk) { \
-                patch_piece(tap, cpar ^ 1, pf_s1, pf_soff); \
-                after = 1; \
-            } \
-            bool counted = true; \
-            if (tap == 0 && pending) { \
-                const bool full = epilogue(pend_tile); \
-                if (full) after += S; \
-                else counted = false; \
-                pending = false; \
-            } \
+// MFMAs of one tap: patch fragments at the tap's shifted rows, weight fragments from the 128-byte slice at BSP
+#define PATCH_TAP(TAP, BSP)                                                                                             \
             { \
-                const unsigned char* Bs = bt0 + bpar * B_BYTES; \
+                constexpr int tky = (TAP) / 3, tkx = (TAP) - tky * 3; \
+                const unsigned char* Bs = (BSP); \
                 u32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT]; \
                 int pa0, pa1; \
                 if constexpr (LIN) { \
-                    const int r0 = lin_row + ky * lin_wp + kx, sw = (r0 >> 1) & 7; \
+                    const int r0 = lin_row + tky * lin_wp + tkx, sw = (r0 >> 1) & 7; \
                     pa0 = r0 * BKB + ((fq ^ sw) << 4); \
                     pa1 = r0 * BKB + (((4 + fq) ^ sw) << 4); \
                 } else { \
-                    pa0 = abase[kx][0] + ky * PW * BKB; \
-                    pa1 = abase[kx][1] + ky * PW * BKB; \
+                    pa0 = abase[tkx][0] + tky * PW * BKB; \
+                    pa1 = abase[tkx][1] + tky * PW * BKB; \
                 } \
 _Pragma("unroll") \
                 for (int i = 0; i < MT; ++i) fa0[i] = *(const u32x4*)(pt + pa0 + i * PSTEP); \
@@ -113,12 +95,72 @@ _Pragma("unroll") \
                     for (int j = 0; j < NT; ++j) Frag<T>::mma(fb1[j], fa1[i], acc[i][j]); \
                 __builtin_amdgcn_s_setprio(0); \
                 __builtin_amdgcn_sched_barrier(0); \
+            }
+
+// One K step (chunk, tap) of the main loop with the tap as a compile-time constant; expanded nine times in the kernel so
+// that every LDS fragment address is a per-lane constant plus an immediate (a lambda here kept the accumulators in memory).
+#define PATCH_STEP(TAP)                                                                                                 \
+    {                                                                                                               \
+        constexpr int tap = TAP;                                                                                    \
+            const int bpar = (cpar ^ tap) & 1; \
+            int after = 0; \
+            if (tap < 8) b_tile(bpar ^ 1, b_koff(kb_cur, tap + 1)); \
+            else if (next_chunk) b_tile(bpar ^ 1, b_koff(kb_next, 0)); \
+            if (tap < PIECES && next_chunk) { \
+                patch_piece(tap, cpar ^ 1, pf_s1, pf_soff); \
+                after = 1; \
             } \
+            bool counted = true; \
+            if (tap == 0 && pending) { \
+                const bool full = epilogue(pend_tile); \
+                if (full) after += S; \
+                else counted = false; \
+                pending = false; \
+            } \
+            PATCH_TAP(TAP, bt0 + bpar * B_BYTES) \
             if (!counted) WAIT_VM(0); \
             else if (after == 0) WAIT_VM(0); \
             else if (after == 1) WAIT_VM(1); \
             else if (after == S) WAIT_VM(S); \
             else WAIT_VM(S + 1); \
+            __builtin_amdgcn_s_barrier(); \
+            asm volatile("" ::: "memory"); \
+    }
+
+// 64-column tiles (BN == 64): a tap is only 16 MFMAs per wave, and a K step costs about as much in DMA issue, waits and the
+// barrier as those take.  There the taps go in pairs -- steps (0,1) (2,3) (4,5) (6,7) (8) of a chunk, five barriers instead of
+// nine -- with both taps' weight slices side by side in a buffer twice as wide (same LDS as the 128-column kernel).
+#define PATCH_DSTEP(SI)                                                                                                 \
+    {                                                                                                               \
+        constexpr int si = SI, t0 = 2 * si, t1 = 2 * si + 1;                                                        \
+            const int bpar = (cpar ^ si) & 1; \
+            int after = 0; \
+            if (si < 4) { \
+                b_tile2(bpar ^ 1, 0, b_koff(kb_cur, t0 + 2)); \
+                if (t1 + 2 <= 8) b_tile2(bpar ^ 1, 1, b_koff(kb_cur, t1 + 2 <= 8 ? t1 + 2 : 0)); \
+            } else if (next_chunk) { \
+                b_tile2(bpar ^ 1, 0, b_koff(kb_next, 0)); \
+                b_tile2(bpar ^ 1, 1, b_koff(kb_next, 1)); \
+            } \
+            if (si < 3 && next_chunk) { \
+                patch_piece(2 * si, cpar ^ 1, pf_s1, pf_soff); \
+                patch_piece(2 * si + 1, cpar ^ 1, pf_s1, pf_soff); \
+                after = 2; \
+            } \
+            bool counted = true; \
+            if (si == 0 && pending) { \
+                const bool full = epilogue(pend_tile); \
+                if (full) after += S; \
+                else counted = false; \
+                pending = false; \
+            } \
+            PATCH_TAP(t0, bt0 + (bpar * 2) * B_BYTES) \
+            if (t1 <= 8) PATCH_TAP((t1 <= 8 ? t1 : 0), bt0 + (bpar * 2 + 1) * B_BYTES) \
+            if (!counted) WAIT_VM(0); \
+            else if (after == 0) WAIT_VM(0); \
+            else if (after == 2) WAIT_VM(2); \
+            else if (after == S) WAIT_VM(S); \
+            else WAIT_VM(S + 2); \
             __builtin_amdgcn_s_barrier(); \
             asm volatile("" ::: "memory"); \
     }
@@ -253,6 +295,12 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
     auto b_koff = [&](int kb, int tap) -> int {
         const int u = tap / 3, v = tap - u * 3;
         return kb + (S2D ? 12 * u + 2 * v : tap) * kstride;
+    };
+    constexpr bool DBL = BN == 64;  // taps in pairs, see PATCH_DSTEP
+    auto b_tile2 = [&](int buf, int slice, int koff) {
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(bt0 + (buf * 2 + slice) * B_BYTES + wave * 1024 + i * 4096), 16, (int)boff[i], koff, 0, 0);
     };
     auto b_tile = [&](int buf, int koff) {
 #pragma unroll
@@ -416,7 +464,12 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
     chunk_src(pf_cc, pf_s1, pf_soff);
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) patch_piece(i, 0, pf_s1, pf_soff);
-    b_tile(0, b_koff(kbase(0), 0));
+    if constexpr (DBL) {
+        b_tile2(0, 0, b_koff(kbase(0), 0));
+        b_tile2(0, 1, b_koff(kbase(0), 1));
+    } else {
+        b_tile(0, b_koff(kbase(0), 0));
+    }
     // advance the prefetch cursor to chunk 1
     auto pf_advance = [&]() {
         if (++pf_cc == p.nchunks) {
@@ -440,7 +493,11 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
         // weight offsets of this chunk and of the one after it (for the weights of its first tap)
         const int kb_cur = kbase(cur_cc);
         const int kb_next = kbase(cur_cc + 1 == p.nchunks ? 0 : cur_cc + 1);
-        PATCH_STEP(0) PATCH_STEP(1) PATCH_STEP(2) PATCH_STEP(3) PATCH_STEP(4) PATCH_STEP(5) PATCH_STEP(6) PATCH_STEP(7) PATCH_STEP(8)
+        if constexpr (DBL) {
+            PATCH_DSTEP(0) PATCH_DSTEP(1) PATCH_DSTEP(2) PATCH_DSTEP(3) PATCH_DSTEP(4)
+        } else {
+            PATCH_STEP(0) PATCH_STEP(1) PATCH_STEP(2) PATCH_STEP(3) PATCH_STEP(4) PATCH_STEP(5) PATCH_STEP(6) PATCH_STEP(7) PATCH_STEP(8)
+        }
         if (next_chunk) pf_advance();
         if (++cur_cc == p.nchunks) {
             cur_cc = 0;
@@ -455,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
 template <typename T, typename OutT, int BN, int MC, int ACT, bool S2D, bool LIN = false>
 int launch_patch_s2d(const PatchQ& p, hipStream_t st) {
     auto kernel = conv_patch_kernel<T, OutT, BN, MC, ACT, S2D, LIN>;
-    constexpr int LDS = 2 * PATCH_BYTES + 2 * BN * BKB;
+    constexpr int LDS = 2 * PATCH_BYTES + (BN == 64 ? 4 : 2) * BN * BKB;
     static int cached[16] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
