@@ -1,7 +1,8 @@
 """Headline benchmark: images/s of forward + decode_outputs + post_process (NMS), CCNet `network.net.Net`
 (s size, 6 classes) at 640x640, 64 images per GPU, bf16 storage / fp32 accumulate, synthetic images and weights.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]      (N > 1 without WORLD_SIZE in the environment: this process starts
+                                                          N child ranks itself, before it touches the GPU, and relays rank 0's line)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...     (one rank per GPU, weak scaling)
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events around every conv launch of one extra
@@ -200,9 +201,38 @@ def kernel_rooflines(ms, infos, precision, outs, B, S, nc, conf, nms_thr, dev):
     return out
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: start N fresh child processes of this same command, one rank per
+    GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would set them), wait for all
+    of them and exit with the first failure.  The parent never initialises the GPU (torch.cuda.device_count() does not)."""
+    import socket
+    import subprocess
+    rehearse = os.environ.get("CCNET_BENCH_REHEARSE", "0") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not rehearse:
+        sys.exit("bench.py --gpus %d: only %d GPU(s) visible (CCNET_BENCH_REHEARSE=1 runs every rank on cuda:0 with gloo, "
+                 "a control-flow rehearsal whose numbers mean nothing)" % (n, have))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p_ in procs:
+        rc = rc or p_.wait()
+    sys.exit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and "WORLD_SIZE" in os.environ and int(os.environ.get("RANK", "0")) == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; the launcher's world size is used" % (args.gpus, world), file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
@@ -221,7 +251,8 @@ def main():
     torch.cuda.set_device(dev)
 
     from ccnet_amd import synth
-    from ccnet_amd.parallel import sharded_post_process
+    from ccnet_amd.parallel import all_gather_detections, sharded_post_process
+    host_exchange = os.environ.get("CCNET_BENCH_EXCHANGE", "device") == "host"   # fallback: round 1's host-side all_gather
     from ccnet_amd.utils import bbox
 
     B, S = args.batch, args.size
@@ -242,6 +273,8 @@ def main():
     def step():
         outs = net(x)
         dec = bbox.decode_outputs(outs, [S, S])
+        if world > 1 and host_exchange:
+            return all_gather_detections(bbox.post_process(dec, 6, [S, S], info, args.conf, args.nms), device=cdev, max_local=B)
         if world > 1:
             # local filter + NMS, then ONE all_gather of the device result buffer (RCCL with the nccl backend) and one D2H copy
             return sharded_post_process(dec, 6, [S, S], info, args.conf, args.nms)
@@ -361,12 +394,13 @@ def main():
             print("  op %3d %-9s %7.3f ms %7.1f TF/s %7.1f GB/s  %8.2f GF %8.2f MB" % (i, names.get(k, k), m, f / (m * 1e-3) / 1e12,
                                                                                      b / (m * 1e-3) / 1e9, f / 1e9, b / 1e6), file=sys.stderr)
 
-    out = {"metric": "images/sec (fwd+decode+NMS) 640x640 bs64 per GPU", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+    out = {"metric": "images/sec (fwd+decode+NMS) %dx%d bs%d per GPU" % (S, S, B), "value": round(value, 2), "unit": "images/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
            "config": {"workload": "CCNet %s (s: depth 0.33, width 0.5, 6 classes) %dx%d, %d images/GPU, fwd+decode+post_process "
                                   "(conf %.3g, nms %.3g)%s" % (args.kind, S, S, B, args.conf, args.nms,
-                                                                ", all_gather of detections" if world > 1 else ""),
+                                                                (", all_gather of detections (%s)" % ("host buffers" if host_exchange else "gloo rehearsal on one GPU" if rehearse
+                                                                                              else "RCCL all_gather_into_tensor")) if world > 1 else ""),
                       "global_batch": world * B, "parallelism": "batch-sharded replicas x%d" % world,
                       "detections_last_step": int(sum(0 if d is None else d.shape[0] for d in dets)),
                       "step_loop": ("pipelined: forward + decode + filter + NMS + D2H of step i are submitted before the detections of step "

@@ -17,6 +17,7 @@
 // bf16 rounding points are those of the separate launches (every intermediate is rounded when it is stored).
 // Weights: MFMA fragments ([n-tile][k-step][64 lanes][8]) packed by ccnet_amd/ops.py:pack_csp, read from L2 by the wave that
 // owns the n-tile, one k-step ahead of the MFMAs.
+#include <mutex>
 #include "common.h"
 
 namespace {
@@ -364,18 +365,35 @@ template <int H16, bool SHORTCUT, bool WLDS, int NWV = CSP_WAVES>
 int launch_csp(const CspP& p, hipStream_t st, int wbytes) {
     auto kernel = csp_fused_kernel<H16, SHORTCUT, WLDS, NWV>;
     const int LDS = XB_BYTES + MROWS * 32 * H16 + 128 * 32 * H16 + (WLDS ? wbytes : 0);
-    static int cached[16] = {0}, cached_lds[16] = {0};
+    // The function's dynamic-LDS limit is set ONCE per device to the most this instantiation can ever ask for (WLDS layers differ in
+    // cin and so in LDS bytes: setting it per launch would let two host threads interleave set(small) / set(big) / launch(big)).
+    // The resident-workgroup count is cached per LDS size, under a lock.
+    constexpr int LDS_CAP = WLDS ? 80 * 1024 : XB_BYTES + MROWS * 32 * H16 + 128 * 32 * H16;
+    if (LDS > LDS_CAP) return ccnet_set_error(CCNET_EINVAL, "csp_fused: %d bytes of LDS exceed the %d this kernel is set up for", LDS, LDS_CAP);
+    struct Entry { int lds, grid; };
+    static std::mutex mu;
+    static bool attr_set[16] = {false};
+    static Entry cache[16][4] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (cached[dev] == 0 || cached_lds[dev] != LDS) {
-        CC_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, NWV * 64, LDS) != hipSuccess || per_cu < 1) per_cu = 1;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        cached[dev] = per_cu * cus;
-        cached_lds[dev] = LDS;
+    int grid = 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_set[dev]) {
+            CC_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CAP));
+            attr_set[dev] = true;
+        }
+        int slot = 0;
+        for (; slot < 4 && cache[dev][slot].lds != 0 && cache[dev][slot].lds != LDS; ++slot) {}
+        if (slot == 4) slot = 0;   // more than four distinct cin per device: recompute into the first slot
+        if (cache[dev][slot].lds != LDS) {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, NWV * 64, LDS) != hipSuccess || per_cu < 1) per_cu = 1;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+            cache[dev][slot] = Entry{LDS, per_cu * cus};
+        }
+        grid = cache[dev][slot].grid;
     }
-    int grid = cached[dev];
     if ((unsigned)grid > p.ntiles) grid = (int)p.ntiles;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(NWV * 64), LDS, st, p);
     CC_LAUNCH_CHECK();

@@ -1116,6 +1116,14 @@ extern "C" int ccnet_nms_noalloc(const float* cand_dev, const int32_t* counts_de
     CC_REQUIRE(need <= NMS_SCRATCH_BYTES,
                "nms_noalloc: B=%d x nmax=%d needs %zu bytes of workspace, the static scratch holds %zu; use ccnet_nms with a caller workspace", B,
                nmax, need, (size_t)NMS_SCRATCH_BYTES);
+    if (stream != nullptr) {   // the scratch pointer below belongs to the CURRENT device: a stream of another GPU would get the wrong one
+        int cur = -1;
+        hipDevice_t sdev = -1;
+        CC_HIP(hipGetDevice(&cur));
+        CC_HIP(hipStreamGetDevice((hipStream_t)stream, &sdev));
+        CC_REQUIRE((int)sdev == cur, "nms_noalloc: the stream belongs to device %d but device %d is current; make the stream's device current first",
+                   (int)sdev, cur);
+    }
     unsigned char* ptr = nullptr;
     const int rc = scratch_for_current_device(&ptr);
     if (rc != CCNET_OK) return rc;

@@ -84,6 +84,28 @@ def all_gather_detections(local, group=None, device=None, max_local=None):
 # buffer.  With the nccl backend (= RCCL over xGMI) the collective runs on the process group's own stream behind the NMS
 # kernels, so no host round trip sits between the local NMS and the exchange (off the forward's critical path).
 _rows_guess = {}
+_buffers = {}   # (key, nmax, stream) -> the call's device buffers, kept between calls (a step allocates nothing in steady state)
+
+
+def _exchange_buffers(key, nmax, B, A, bmax, world, dev, on_device):
+    from . import ops
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    k = (key, nmax, stream)
+    got = _buffers.get(k)
+    if got is None:
+        if len(_buffers) > 16:
+            _buffers.clear()
+        n_rows = bmax * nmax * 7
+        ws = torch.empty(ops.nms_workspace_bytes(max(B, 1), nmax) + 256, dtype=torch.uint8, device=dev)
+        got = {"cand": torch.empty(max(B, 1), A, 7, dtype=torch.float32, device=dev),
+               # rows (bmax, nmax, 7) | keep counts (bmax) | candidate counts (bmax); zeroed once: the rows and counts of the
+               # padding images (uneven shards) are never written afterwards, everything else is rewritten by every call
+               "both": torch.zeros(n_rows + 2 * bmax, dtype=torch.float32, device=dev),
+               "gathered": torch.empty(world * (n_rows + 2 * bmax), dtype=torch.float32, device=dev) if on_device else None,
+               "keep_idx": torch.empty(max(B, 1), nmax, dtype=torch.int32, device=dev),
+               "ws": ws[(-ws.data_ptr()) % 256:]}
+        _buffers[k] = got
+    return got
 
 
 def sharded_post_process(prediction, num_classes, input_shape, image_info, conf_thres=0.5, nms_thres=0.4, group=None,
@@ -92,10 +114,13 @@ def sharded_post_process(prediction, num_classes, input_shape, image_info, conf_
     CUDA tensor of the local images, image_info: their [name, iw, ih] rows.  Returns the list for the WHOLE batch in rank
     order on every rank (same row contents as ccnet_amd.utils.bbox.post_process on the unsharded batch for the
     shard-invariant nets).  total_images: size of the whole batch when the shards are uneven (shard_range); default: every
-    rank holds B_local images.  Without an initialised process group this is plain post_process."""
+    rank holds B_local images.  Without an initialised process group this is plain post_process; with one, the exchange runs
+    even at world size 1 (a one-rank RCCL group executes the same all_gather_into_tensor, tests/test_parallel_gpu.py).
+    The device buffers are kept between calls per (shard layout, row estimate, stream): calls on ONE stream are serialised by
+    the device->host copy at the end, callers on different streams get their own buffers."""
     from . import ops
     from .utils import bbox
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return bbox.post_process(prediction, num_classes, input_shape, image_info, conf_thres, nms_thres)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     B, A = int(prediction.shape[0]), int(prediction.shape[1])
@@ -113,25 +138,22 @@ def sharded_post_process(prediction, num_classes, input_shape, image_info, conf_
     key = (tuple(locals_), A, str(dev))
     nmax = min(_rows_guess.get(key, ROWS_GUESS), max(A, 1))
     with torch.cuda.device(dev):
-        cand = torch.empty(max(B, 1), A, 7, dtype=torch.float32, device=dev)
-        counts0 = torch.zeros(bmax, dtype=torch.int32, device=dev)
-        if B and A:
-            ops.filter_candidates(pred, num_classes, conf_thres, cand, counts0[:B])
+        first = True
         while True:
-            # rows (bmax, nmax, 7) | keep counts (bmax) | candidate counts (bmax): padding images carry zeros
-            n_rows = bmax * nmax * 7
-            both = torch.zeros(n_rows + 2 * bmax, dtype=torch.float32, device=dev)
-            both[n_rows + bmax:].view(torch.int32).copy_(counts0)
+            buf = _exchange_buffers(key, nmax, B, A, bmax, world, dev, on_device)
+            both, n_rows = buf["both"], bmax * nmax * 7
+            cnt = both[n_rows + bmax:].view(torch.int32)   # candidate counts, int32 bit patterns in the fp32 buffer
             if B and A:
-                ws = torch.empty(ops.nms_workspace_bytes(B, nmax) + 256, dtype=torch.uint8, device=dev)
-                ws = ws[(-ws.data_ptr()) % 256:]
-                keep_idx = torch.empty(B, nmax, dtype=torch.int32, device=dev)
-                ops.nms(cand, counts0[:B], nmax, nms_thres, hw, both[:B * nmax * 7].view(B, nmax, 7), keep_idx,
-                        both[n_rows:n_rows + B].view(torch.int32), ws)
+                if first:
+                    ops.filter_candidates(pred, num_classes, conf_thres, buf["cand"], cnt[:B])
+                    cand, first = buf["cand"], False
+                else:
+                    cnt[:B].copy_(cnt0)
+                ops.nms(cand, cnt[:B], nmax, nms_thres, hw, both[:B * nmax * 7].view(B, nmax, 7), buf["keep_idx"],
+                        both[n_rows:n_rows + B].view(torch.int32), buf["ws"])
             if on_device:
-                gathered = torch.empty(world * both.numel(), dtype=torch.float32, device=dev)
-                dist.all_gather_into_tensor(gathered, both, group=group)  # RCCL, ordered behind the NMS kernels
-                host = gathered.cpu().numpy().reshape(world, -1)
+                dist.all_gather_into_tensor(buf["gathered"], both, group=group)  # RCCL, ordered behind the NMS kernels
+                host = buf["gathered"].cpu().numpy().reshape(world, -1)
             else:  # gloo (CPU tests, one-GPU rehearsal): the same buffer travels through the host
                 mine = both.cpu()
                 parts = [torch.empty_like(mine) for _ in range(world)]
@@ -144,6 +166,7 @@ def sharded_post_process(prediction, num_classes, input_shape, image_info, conf_
                 _rows_guess.clear()
             if cmax <= nmax:
                 break
+            cnt0 = cnt[:B].clone() if B and A else None   # the retry's buffers are other buffers: carry the counts over
             nmax = min(cmax, A)
     out = []
     for r in range(world):

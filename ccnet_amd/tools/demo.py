@@ -33,19 +33,35 @@ def predict(model, images, num_classes, input_shape, image_info, conf_thres, nms
         return post_process(outputs, num_classes, input_shape, image_info, conf_thres=conf_thres, nms_thres=nms_thres)
 
 
-def inference(model, image, input_shape, conf_thres, nms_thres, device, num_classes=None, class_names=None, draw=None):
-    """Reference signature plus optional keyword arguments for what the reference reads from module globals
-    (num_classes, class_names, tools/demo.py:72,80).  Returns the image (drawn on when `draw` is given) -- or, when
-    `draw` is None, the list of detections."""
+# The reference reads these two as module globals inside inference() (tools/demo.py:72,80; its __main__ sets them, :92).  A
+# caller that imports the module may set them here the same way; otherwise they are taken from the model.
+num_classes = None
+class_names = None
+
+
+def detect(model, image, input_shape, conf_thres, nms_thres, device, num_classes=None):
+    """inference() without the drawing: returns (results, image_info) -- results is post_process' list with one
+    (n, 7) float32 array [top, left, bottom, right, obj_conf, class_conf, class_id] for the one image."""
     data, image_info = preprocess(image, input_shape)
     images = torch.from_numpy(data).to(device)
     if num_classes is None:
-        num_classes = model._cfg["nc"]
-    results = predict(model, images, num_classes, input_shape, image_info, conf_thres, nms_thres)
-    if draw is None:
-        return results
+        num_classes = globals()["num_classes"] or model._cfg["nc"]
+    return predict(model, images, num_classes, input_shape, image_info, conf_thres, nms_thres), image_info
+
+
+def inference(model, image, input_shape, conf_thres, nms_thres, device, num_classes=None, class_names=None, draw=None):
+    """tools/demo.py:28-81, same six positional arguments, same return value: the IMAGE, with the detections drawn on it
+    in place by utils.util.draw_rectangle (:80) -- or untouched when post_process returns None for it (:77-79).  The
+    reference takes num_classes / class_names from module globals; here keyword arguments, then this module's globals of the
+    same names, then the model's own class count and the class ids as names.  `draw` replaces draw_rectangle (same
+    arguments).  detect() is the variant that returns the detections."""
+    results, image_info = detect(model, image, input_shape, conf_thres, nms_thres, device, num_classes)
     if results[0] is None:
         return image
+    if class_names is None:
+        class_names = globals()["class_names"] or [str(i) for i in range(model._cfg["nc"])]
+    if draw is None:
+        from ..utils.util import draw_rectangle as draw
     draw(results, image, image_info[0][1], image_info[0][2], input_shape, class_names)
     return image
 

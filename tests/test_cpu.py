@@ -484,6 +484,54 @@ def test_compat_shim_resolves_reference_import_lines():
     assert r.returncode == 0 and "shim ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_demo_inference_returns_the_drawn_image_through_the_shim():
+    """tools/demo.py:28-81 through compat/: the reference's six positional arguments, and the return value is the IMAGE
+    (the same array, drawn on in place by draw_rectangle) -- `image = inference(...); cv2.imshow("image", image)` keeps
+    working.  OpenCV is absent: a stand-in cv2 records the drawing calls; the three hot-path statements need a GPU, so
+    predict() is replaced by canned post_process output here (tests/test_forward_gpu.py runs the real one)."""
+    import subprocess
+    code = (
+        "import sys, types, numpy as np\n"
+        "calls = []\n"
+        "cv2 = types.ModuleType('cv2'); cv2.INTER_CUBIC = 2; cv2.FONT_HERSHEY_SIMPLEX = 0\n"
+        "cv2.resize = lambda img, size, interpolation=None: np.zeros((size[1], size[0], 3), np.uint8)\n"
+        "cv2.getTextSize = lambda text, font, scale, thick: ((len(text) * 6, 8), 3)\n"
+        "def rectangle(img, p0, p1, colour, thickness=1):\n"
+        "    calls.append(('rect', p0, p1)); img[p0[1]:p1[1] + 1, p0[0]:p1[0] + 1] = 255\n"
+        "cv2.rectangle = rectangle\n"
+        "cv2.putText = lambda img, text, org, font, scale, colour, thickness=1: calls.append(('text', text, org))\n"
+        "sys.modules['cv2'] = cv2\n"
+        "import tools.demo as demo\n"
+        "from tools.demo import inference\n"
+        "class M:\n"
+        "    _cfg = {'nc': 6}\n"
+        "rows = np.array([[10.7, 20.2, 50.9, 80.1, 0.9, 0.8, 3.0], [-4.0, 5.0, 300.0, 999.0, 0.5, 0.5, 0.0]], np.float32)\n"
+        "seen = {}\n"
+        "def fake_predict(model, images, num_classes, input_shape, image_info, conf_thres, nms_thres):\n"
+        "    seen.update(nc=num_classes, info=image_info, shape=tuple(images.shape), conf=conf_thres, nms=nms_thres)\n"
+        "    return [rows]\n"
+        "demo.predict = fake_predict\n"
+        "image = np.zeros((120, 160, 3), np.uint8)\n"
+        "out = inference(M(), image, [224, 224], 0.5, 0.6, 'cpu')\n"
+        "assert out is image and out.any(), 'the reference returns the image it drew on'\n"
+        "assert seen == dict(nc=6, info=[[0, 160, 120]], shape=(1, 3, 224, 224), conf=0.5, nms=0.6), seen\n"
+        "assert ('rect', (20, 10), (80, 50)) in calls and ('rect', (5, 0), (160, 120)) in calls, calls   # floor, clipped to the image\n"
+        "assert [c[1] for c in calls if c[0] == 'text'] == ['3:72.0%', '0:25.0%'], calls\n"
+        "demo.class_names = ['a', 'b', 'c', 'd', 'e', 'f']; demo.num_classes = 6; del calls[:]   # the reference's module globals\n"
+        "inference(M(), image, [224, 224], 0.5, 0.6, 'cpu')\n"
+        "assert [c[1] for c in calls if c[0] == 'text'] == ['d:72.0%', 'a:25.0%'], calls\n"
+        "demo.predict = lambda *a: [None]\n"
+        "blank = np.zeros((8, 8, 3), np.uint8)\n"
+        "assert inference(M(), blank, [224, 224], 0.5, 0.6, 'cpu') is blank and not blank.any()\n"
+        "demo.predict = fake_predict\n"
+        "res, info = demo.detect(M(), image, [224, 224], 0.5, 0.6, 'cpu')\n"
+        "assert res[0] is rows and info == [[0, 160, 120]]\n"
+        "print('demo ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "compat") + os.pathsep + ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0 and "demo ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_socket_server_validates_client_sizes_and_bounds_its_caches(tmp_path):
     """input_shape comes from the client and every distinct size compiles a plan: sizes are validated before anything is
     allocated; the model cache is an LRU keyed by the checkpoint's path, mtime and size."""

@@ -325,6 +325,34 @@ def test_socket_request_runs_the_hot_path(tmp_path, monkeypatch):
     assert s2s._model_for(path, 6, "cuda") is model
 
 
+def test_demo_inference_draws_what_the_hot_path_found(monkeypatch):
+    """tools/demo.py:28-81 on the GPU with the reference's six positional arguments: the return value is the image, and what
+    was drawn on it is post_process' output for the same prepared input (a stand-in cv2 records the boxes)."""
+    import sys
+    import types
+    from ccnet_amd.tools import demo
+    from oracle import preprocess_oracle as po
+    boxes = []
+    fake = types.ModuleType("cv2")
+    fake.INTER_CUBIC, fake.FONT_HERSHEY_SIMPLEX = 2, 0
+    fake.resize = lambda img, size, interpolation=None: po.resize_bicubic_u8(img, size[0], size[1])
+    fake.getTextSize = lambda text, font, scale, thick: ((len(text) * 6, 8), 3)
+    fake.rectangle = lambda img, p0, p1, colour, thickness=1: boxes.append((p0, p1, thickness))
+    fake.putText = lambda *a, **k: None
+    monkeypatch.setitem(sys.modules, "cv2", fake)
+    net = _model("net", 0.33, 0.5, 6, "fp32")
+    image = np.random.default_rng(5).integers(0, 256, (200, 260, 3), dtype=np.uint8)
+    out = demo.inference(net, image, [224, 224], 0.3, 0.6, "cuda")
+    assert out is image
+    res, info = demo.detect(net, image, [224, 224], 0.3, 0.6, "cuda")
+    assert info == [[0, 260, 200]] and res[0].shape[0] > 0
+    frames = [b for b in boxes if b[2] == 2]
+    assert len(frames) == res[0].shape[0]
+    for (p0, p1, _), row in zip(frames, res[0]):
+        assert p0 == (max(0, int(np.floor(row[1]))), max(0, int(np.floor(row[0]))))
+        assert p1 == (min(260, int(np.floor(row[3]))), min(200, int(np.floor(row[2]))))
+
+
 def test_headline_config_full_size_properties():
     """BASELINE configs[1] as bench.py runs it (`net`, s, 6 classes, 640^2, 64 images, bf16, conf 0.5 / nms 0.6), checked
     through size-independent properties: (1) decode of the device logits equals the oracle's decode of the same logits

@@ -1,7 +1,8 @@
 """Multi-GPU data path rehearsed on one GPU: two fresh child processes, each on cuda:0 with the gloo backend, run their
 shard_range halves of a net_deploy batch (forward -> decode -> sharded_post_process); the gathered detections must equal
-the single-process run of the whole batch bit for bit (net_deploy is per-image independent).  The exchange is
-unmeasured on multi-GPU hardware until a SCALE record exists."""
+the single-process run of the whole batch bit for bit (net_deploy is per-image independent).  The RCCL branch
+(all_gather_into_tensor of the device result buffer) runs in a ONE-rank nccl group on the one-GPU box and in a two-rank
+group where two GPUs are visible.  The exchange is unmeasured on multi-GPU hardware until a SCALE record exists."""
 import os
 import subprocess
 import sys
@@ -14,12 +15,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("total,conf", [(6, 0.5), (5, 0.01)])  # even shards; uneven shards with more candidates per image than the first row estimate
-def test_sharded_forward_equals_unsharded(tmp_path, total, conf):
+def _want(total, size, conf):
     from ccnet_amd import synth
     from ccnet_amd.network.net_deploy import Net
     from ccnet_amd.utils import bbox
-    size, world = 224, 2
     net = Net(0.33, 0.5, 6, "silu")
     net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=0, bn_calib="net_deploy"))
     net = net.to("cuda").eval().set_precision("bf16")
@@ -27,16 +26,50 @@ def test_sharded_forward_equals_unsharded(tmp_path, total, conf):
     info = [[i, size + 3 * i, size - 2 * i] for i in range(total)]
     want = bbox.post_process(bbox.decode_outputs(net(x), [size, size]), 6, [size, size], info, conf, 0.6)
     torch.cuda.synchronize()
+    return want
+
+
+def _run_ranks(tmp_path, world, total, size, conf, backend):
     port = 29500 + (os.getpid() % 2000)
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "scripts", "sharded_forward_check.py"), str(tmp_path / ("r%d.npz" % r)),
-                                       str(total), str(size), str(conf)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+                                       str(total), str(size), str(conf), backend], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=240)[0].decode("utf-8", "replace") for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-2000:]
+
+
+# even shards; uneven shards with more candidates per image than the first row estimate
+@pytest.mark.parametrize("total,conf", [(6, 0.5), (5, 0.01)])
+def test_sharded_forward_equals_unsharded(tmp_path, total, conf):
+    size, world = 224, 2
+    want = _want(total, size, conf)
+    _run_ranks(tmp_path, world, total, size, conf, "gloo")
+    _check(tmp_path, world, want)
+
+
+def _check(tmp_path, world, want):
     for r in range(world):
         z = np.load(tmp_path / ("r%d.npz" % r))
         assert list(z["counts"]) == [w.shape[0] for w in want]
         assert np.array_equal(z["rows"], np.concatenate(want, 0))
+
+
+@pytest.mark.parametrize("total,conf", [(4, 0.5), (3, 0.01)])
+def test_rccl_exchange_one_rank_group(tmp_path, total, conf):
+    """The nccl (= RCCL) branch of sharded_post_process on hardware: a one-rank group on cuda:0 runs filter + NMS into the
+    device result buffer, all_gather_into_tensor of it, one D2H copy; equal to post_process bit for bit (the second case
+    overflows the first row estimate and takes the exact re-launch)."""
+    want = _want(total, 224, conf)
+    _run_ranks(tmp_path, 1, total, 224, conf, "nccl")
+    _check(tmp_path, 1, want)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's 8-GPU node; the builder's box has one)")
+@pytest.mark.parametrize("total,conf", [(6, 0.5), (5, 0.01)])
+def test_rccl_exchange_two_ranks(tmp_path, total, conf):
+    want = _want(total, 224, conf)
+    _run_ranks(tmp_path, 2, total, 224, conf, "nccl")
+    _check(tmp_path, 2, want)
