@@ -219,7 +219,13 @@ def spawn_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        # rank 0's stdout is read here so that exactly its JSON line reaches this process' stdout (gloo and RCCL print
+        # connection notes of their own on stdout); everything else goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    for line in procs[0].stdout:
+        (sys.stdout if line.startswith('{"metric"') else sys.stderr).write(line)
+        sys.stdout.flush()
     rc = 0
     for p_ in procs:
         rc = rc or p_.wait()

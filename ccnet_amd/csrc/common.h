@@ -82,13 +82,15 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float x) {
     __bf16 h = (__bf16)x;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return (uint32_t)__builtin_bit_cast(unsigned short, h);
 }
-// Two floats -> one packed pair, each half converted on its own.  (The vector form -- __builtin_convertvector of a float2, one
-// v_cvt_pk_bf16_f32 with two sources instead of two conversions, a shift and an OR -- was tried in every epilogue: it made the
-// fused Transformer's in-place LayerNorm run-to-run different on tokens 48..63 (scripts/tf_det_probe.py; cured by an
-// instruction barrier in front of the conversion, not reproduced by an isolated pk_fma -> cvt_pk test), for 0.2 % of the step.
-// Not understood, so not used.)
+// Two floats -> one packed pair with ONE v_cvt_pk_bf16_f32 (RNE, NaN stays NaN).  Round 2 saw the fused Transformer become
+// run-to-run different with this form and kept two scalar conversions; the cause was not the conversion but register allocation:
+// the shorter code put LayerNorm's mean into an odd register and LLVM broadcast it with `op_sel:[0,1]`, a packed-fp32 operand form
+// that reads zero in lanes 48..63 beside another wave's MFMAs (scripts/hazard/, scripts/check_isa.py lints every build).
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const bf16x2_t h = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, h);
 }
 // 8 consecutive channels <-> fp32
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {

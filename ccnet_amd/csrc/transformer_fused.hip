@@ -113,6 +113,17 @@ __device__ __forceinline__ int opaque(int v) {
 
 __device__ __forceinline__ uint2 pack4(const float* v) { return make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
 
+// A scalar broadcast into BOTH registers of a real 64-bit pair, opaque to the compiler.  Left alone, LLVM broadcasts a scalar into a
+// packed-fp32 op with op_sel; when the scalar sits in the odd register of a pair that is `op_sel:[0,1]` (low lane reads the high
+// dword), and that form reads ZERO in lanes 48..63 while another wave's MFMA runs on the SIMD (scripts/hazard/ln_chain_min.hip,
+// scripts/check_isa.py): LayerNorm's x - mean then silently becomes x - 0 for tokens 48..63.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pair2(float v) {
+    f32x2 p = {v, v};
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
 // workgroup barrier that waits for this wave's LDS traffic only: the weight ring's global loads stay in flight across it
 #define TSYNC() __syncthreads()
 
@@ -185,15 +196,17 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
         const float mean = t1 * (1.0f / E);
         const float var = fmaxf(t2 * (1.0f / E) - mean * mean, 0.0f);
         const float rs = rsqrtf(var + 1e-5f);
-        const float* g = gb + 64 * wave;       // wave-uniform: scalar loads
+        const float* g = gb + 64 * wave;       // wave-uniform
         const float* bt = gb + E + 64 * wave;
+        const f32x2 mean2 = pair2(mean), rs2 = pair2(rs);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             u32x4 pk;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = 8 * q + 2 * e;
-                pk[e] = pack_bf16x2((v[c] - mean) * rs * g[c] + bt[c], (v[c + 1] - mean) * rs * g[c + 1] + bt[c + 1]);
+                const f32x2 y = (f32x2{v[c], v[c + 1]} - mean2) * rs2 * f32x2{g[c], g[c + 1]} + f32x2{bt[c], bt[c + 1]};
+                pk[e] = pack_bf16x2(y.x, y.y);
             }
             if (to_lds) *(u32x4*)(X + xoff(row, 8 * wave + q)) = pk;
             if (to_global && row < p.S) *(u32x4*)(p.out + ((size_t)((size_t)row * p.N + n) * p.out_ld + 64 * wave + 8 * q) * 2) = pk;
@@ -290,8 +303,11 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
             }
             ld_bias(1, bk);
             if (cross) {
-                // vector-memory operations retire in order: the Q projection issued 16 ring refills behind the 8 DMA pieces
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING) : "memory");
+                // every vector-memory operation of this wave so far, the 8 DMA pieces included.  (A counted wait -- vmcnt(RING),
+                // "the Q projection issued 16 ring refills behind the DMA" -- held the ring's newest loads in flight, but it is only
+                // right while the compiler leaves at least RING vector-memory instructions between the DMA and this point; the
+                // spill reloads around here drain the counter anyway, so the exact form costs nothing.)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 TSYNC();  // the staged memory is complete
                 f32x4 acck[4][2], accv[4][2];
                 zero<2>(acck);

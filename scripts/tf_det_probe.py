@@ -7,7 +7,8 @@ net = importlib.import_module("ccnet_amd.network.net").Net(0.33, 0.5, 6, "silu")
 sd = synth.synth_state_dict(net.state_dict(), seed=0, bn_calib="net")
 S, N = 64, 400
 src = (torch.randn(S * N, 256, device="cuda") * 0.7).to(torch.bfloat16)
-for ne, nd in ((1, 0), (0, 1), (6, 6)):
+combos = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(1, 0), (0, 1), (6, 6)]
+for ne, nd in combos:
     sd2 = dict(sd)
     wst, pvec, fpw = ops.pack_transformer(sd2, "dark5.2.transformer", ne, nd, "cuda")
     outs = []

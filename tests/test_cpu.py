@@ -564,3 +564,26 @@ def test_socket_server_validates_client_sizes_and_bounds_its_caches(tmp_path):
         s2s._model_for("", nc, "cpu")
     assert len(s2s._models) == s2s.MAX_MODELS
     s2s._models.clear()
+
+
+def test_isa_lint_refuses_the_op_sel_form_and_passes_the_built_objects(tmp_path):
+    """scripts/check_isa.py: the packed-fp32 operand form that measured wrong on MI355X (low lane reads the high dword of a source
+    pair, profiles/r03_hazard_*.txt) is reported; the forms that measured clean are not; the objects of the built library are clean."""
+    import glob
+    import subprocess
+    lint = os.path.join(ROOT, "scripts", "check_isa.py")
+    bad = tmp_path / "bad.s"
+    bad.write_text("_Zkernel:\n\tv_pk_add_f32 v[0:1], v[70:71], v[74:75] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+                   "\tv_pk_fma_f32 v[4:5], v[4:5], v[28:29], v[24:25] op_sel:[1,0,0]\n")
+    good = tmp_path / "good.s"
+    good.write_text("_Zkernel:\n\tv_pk_mul_f32 v[0:1], v[0:1], v[76:77] op_sel_hi:[1,0]\n\tv_pk_add_f32 v[0:1], v[2:3], v[4:5] neg_lo:[0,1] neg_hi:[0,1]\n"
+                    "\tv_pk_fma_f32 v[24:25], v[4:5], v[36:37], v[24:25] op_sel_hi:[0,1,1]\n")
+    r = subprocess.run([sys.executable, lint, str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stdout.count("low lane reads the high dword") == 2, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, lint, str(good)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == "", r.stdout + r.stderr
+    objs = sorted(glob.glob(os.path.join(ROOT, "ccnet_amd", "csrc", "build", "*.o")))
+    if not objs:
+        pytest.skip("no object files (the library was built elsewhere)")
+    r = subprocess.run([sys.executable, lint] + objs, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
