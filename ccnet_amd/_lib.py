@@ -40,6 +40,9 @@ def lib():
         L.ccnet_device_count.restype = i32
         L.ccnet_conv_pack_dims.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
         L.ccnet_conv2d.argtypes = [C.POINTER(ConvDesc), vp]
+        L.ccnet_conv_halo_stream_elems.argtypes = [i32, i32]
+        L.ccnet_conv_halo_stream_elems.restype = sz
+        L.ccnet_conv_halo.argtypes = [C.POINTER(Slice), i32, i32, i32, i32, i32, i32, vp, vp, i32, Slice, Slice, vp]
         L.ccnet_csp_fused_weight_elems.argtypes = [i32, i32]
         L.ccnet_csp_fused_weight_elems.restype = sz
         L.ccnet_csp_fused.argtypes = [C.POINTER(Slice), i32, i32, i32, i32, i32, i32, i32, vp, vp, Slice, vp]

@@ -244,7 +244,37 @@ class Compiler:
         return pc
 
     # ---- emitters
+    def conv3x3_halo(self, w, b, ins, s2d, act, out=None, residual=None):
+        """3x3 s1 p1 (or SpaceToDepth + 3x3 with the un-shuffled input) on ccnet_conv_halo when the shape qualifies, else None."""
+        if self.dtype != BF16 or os.environ.get("CCNET_NO_HALO_CONV", "0") != "0":
+            return None
+        x0 = ins[0]
+        cout, cvirt = w.shape[0], w.shape[1]
+        Ho, Wo = (x0.H // 2, x0.W // 2) if s2d else (x0.H, x0.W)
+        if s2d and (x0.H % 2 or x0.W % 2 or len(ins) != 1):
+            return None
+        probe_out = out.sl() if out is not None else _lib.Slice(None, cout, 0, cout, 0)
+        if not ops.conv_halo_ok(self.dtype, None, [t.sl() for t in ins], cvirt, cout, probe_out, None if residual is None else residual.sl()):
+            return None
+        # The choice must not depend on the batch size: the two kernels round alike but accumulate in different orders, and image i of
+        # a batch has to equal image i run alone bit for bit (tests/test_forward_gpu.py: batch independence; sharded == unsharded).
+        # 256-position tiles leave the 20 x 20 maps with too few workgroups unless the layer has four column blocks (measured at 64
+        # images: 256 -> 256 is 40 us here and 39 us on ccnet_conv2d's 128-position tiles, 1024 -> 512 is 235 against 241).
+        if Ho * Wo <= 400 and cout < 512 and os.environ.get("CCNET_HALO_SMALL_MAPS", "0") == "0":
+            return None
+        pk = ops.PackedHalo(w, b, self.dev)
+        self.keep.append(pk)
+        if out is None:
+            out = self.new(cout, Ho, Wo)
+        assert (out.H, out.W, out.C) == (Ho, Wo, cout), "conv output slice mismatch"
+        ops.conv_halo([t.sl() for t in ins], pk, s2d, self.B, x0.H, x0.W, out.sl(), act, None if residual is None else residual.sl())
+        return out
+
     def conv_w(self, w, b, ins, stride, pad, act, out=None, residual=None, out_dtype=None):
+        if w.shape[-1] == 3 and w.shape[-2] == 3 and stride == 1 and pad == 1 and out_dtype is None:
+            got = self.conv3x3_halo(w, b, ins, False, act, out, residual)
+            if got is not None:
+                return got
         pc = self.pack(w, b)
         x0 = ins[0]
         H, W = x0.H, x0.W
@@ -268,6 +298,9 @@ class Compiler:
         """SpaceToDepth+BaseConv k3 (net.py) as a 6x6 s2 p2 conv, or BaseConv k3 s2 (other nets)."""
         if self.c["s2d"]:
             w, b = self.folded(p + ".conv")
+            got = self.conv3x3_halo(w, b, [x], True, self.act)
+            if got is not None:
+                return got
             return self.conv_w(ops.s2d_to_6x6(w), b, [x], 2, 2, self.act)
         return self.base_conv(p, [x], 2)
 

@@ -90,6 +90,41 @@ def conv2d(ins, pc, B, H, W, stride, pad, out, act="none", residual=None, out_dt
     return d.Ho, d.Wo
 
 
+HALO_RING = 9  # conv_halo.hip: HRING
+
+
+class PackedHalo:
+    """Register-stream packing of a 3x3 conv for ccnet_conv_halo (include/ccnet_hip.h): w (Cout, Cin, 3, 3) fp64 over the
+    channels the conv sees (SpaceToDepth: the 4C virtual channels, model_block.py:169-173), Cin % 32 == 0, Cout % 64 == 0."""
+
+    def __init__(self, w, b, device):
+        w = w.to(torch.float64)
+        cout, cin, kh, kw = w.shape
+        assert (kh, kw) == (3, 3) and cin % 32 == 0 and cout % 64 == 0
+        self.cout, self.cin = cout, cin
+        # [tap][n64][j][row][cc][kq][e] -> [n64][cc][tap][j][kq][row][e]: per 64 output channels, chunk-major, tap, n-tile; a fragment
+        # is [kq (lane >> 4)][row (lane & 15)][8]
+        f = w.permute(2, 3, 0, 1).reshape(9, cout // 64, 4, 16, cin // 32, 4, 8).permute(1, 4, 0, 2, 5, 3, 6).reshape(cout // 64, -1, 512)
+        f = torch.cat([f, f[:, :HALO_RING]], 1)  # the ring prefetches across the tile boundary: the stream's head again
+        assert f.numel() == int(lib().ccnet_conv_halo_stream_elems(cin, cout))
+        self.weight = f.to(torch.bfloat16).to(device).contiguous()
+        self.bias = None if b is None else b.to(torch.float32).to(device).contiguous()
+
+
+def conv_halo_ok(dtype, out_dtype, ins, cin_virtual, cout, out, residual=None):
+    """Shapes ccnet_conv_halo takes (the C entry point validates again)."""
+    return (dtype == BF16 and (out_dtype is None or out_dtype == BF16) and cout % 64 == 0 and cin_virtual % 32 == 0
+            and all(s.shift == 0 and s.C % 32 == 0 and s.ldc % 8 == 0 and s.coff % 8 == 0 for s in ins)
+            and out.ldc % 4 == 0 and out.coff % 4 == 0 and (residual is None or (residual.ldc % 4 == 0 and residual.coff % 4 == 0)))
+
+
+def conv_halo(ins, pk, s2d, B, H, W, out, act="none", residual=None):
+    arr = (Slice * len(ins))(*ins)
+    check(lib().ccnet_conv_halo(arr, len(ins), 1 if s2d else 0, B, H, W, pk.cout, pk.weight.data_ptr(),
+                                None if pk.bias is None else pk.bias.data_ptr(), ACT[act], null_slice() if residual is None else residual,
+                                out, stream_ptr()))
+
+
 class PackedCsp:
     """Fragment-packed weights of one CSPLayer with a single bottleneck for ccnet_csp_fused (include/ccnet_hip.h):
     mats = [(w OIHW fp64, b fp64)] for [conv1;conv2], bottleneck conv1, bottleneck conv2 (3x3), conv3."""

@@ -80,6 +80,22 @@ typedef struct {
 int ccnet_conv_pack_dims(int dtype, int Cout, int K, int* Cout_pad, int* Kpad);
 int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream);
 
+/* ---- 3x3 Conv-BN-act with register-streamed weights (bf16) -------------------------------------------------
+ * The same operator as ccnet_conv2d for the two shapes that carry most of the network's FLOPs -- BaseConv k3 s1 p1
+ * (network/model_block.py:37-58: Bottleneck.conv2, the head's cls/reg convs, MobileViT.conv4) and SpaceToDepth + BaseConv k3
+ * (:152-175; s2d = 1: `in` is the un-shuffled (B, H, W, C) tensor, the conv runs over the virtual (H/2, W/2, 4C) one with
+ * channel (2dy+dx)*C + c = pixel (2y+dy, 2x+dx), channel c) -- on a different kernel: the halo patch of the input in LDS,
+ * the weights streamed from L2 into registers in consumption order (conv_halo.hip).
+ *   in: 1-2 bf16 slices (channel concat; s2d: exactly one), un-shifted, each a multiple of 32 channels; H, W: stored input size;
+ *   Cout % 64 == 0; out / residual (ptr may be NULL; added after the activation) bf16 with channel offsets % 4 == 0.
+ *   wstream_dev: bf16, ccnet_conv_halo_stream_elems(Cin_virtual, Cout) elements: for each block of 64 output channels, for each
+ *   32-channel chunk, for each tap (ky*3+kx), for each 16-row n-tile: one MFMA A-operand fragment [64 lanes][8] (lane l: row
+ *   l & 15, k (l >> 4)*8..+7), then a copy of the block's first 9 fragments (ccnet_amd/ops.py:PackedHalo).  bias_dev: fp32[Cout] or NULL.
+ * Anything else: CCNET_EINVAL (callers use ccnet_conv2d).  Rounding points are ccnet_conv2d's; the accumulation order differs. */
+size_t ccnet_conv_halo_stream_elems(int Cin_virtual, int Cout);
+int ccnet_conv_halo(const ccnet_slice* in, int nseg, int s2d, int B, int H, int W, int Cout, const void* wstream_dev,
+                    const float* bias_dev, int act, ccnet_slice residual, ccnet_slice out, ccnet_stream stream);
+
 /* ---- a whole CSPLayer with one bottleneck in one launch (bf16) ---------------------------------------------
  * Replaces CSPLayer.forward with n = 1 (network/model_block.py:86-116) and the Bottleneck inside it (:193-218):
  *   x_1 = conv1(x); x_2 = conv2(x); x_1 = [x_1 +] conv_b2(conv_b1(x_1)); out = conv3(cat(x_1, x_2))

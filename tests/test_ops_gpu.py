@@ -244,6 +244,75 @@ def test_s2d_conv_linear_patch_geometry(B, C, H, W, cout):
     assert rel(from_nhwc(out, 0, cout), ref) < tol(1)
 
 
+HALO_CASES = [
+    # B, H, W (stored input), cins, cout, s2d, act, residual          geometry the kernel picks
+    (2, 32, 48, (64,), 128, False, "silu", False),      # 16 x 16 tiles, BN 128
+    (3, 16, 32, (32, 96), 64, False, "none", True),     # two segments, BN 64, residual
+    (2, 24, 40, (128,), 128, False, "silu", True),      # linear (Wp = 42), partial last tile
+    (5, 20, 20, (256,), 256, False, "relu", False),     # linear, two column blocks, tiles straddle images
+    (1, 5, 5, (64,), 64, False, "silu", False),         # one image smaller than a tile
+    (2, 50, 56, (64,), 192, False, "silu", False),      # 16 x 16 tiles with ragged edges in both directions, BN 64 (192 = 3 x 64)
+    (2, 64, 96, (32,), 64, True, "silu", False),        # SpaceToDepth, C = 32: a chunk is one (dy, dx)
+    (3, 40, 40, (64,), 128, True, "silu", False),       # SpaceToDepth to a 20 x 20 map: linear
+    (2, 32, 64, (128,), 256, True, "lrelu", False),     # SpaceToDepth, C = 128: four chunks per (dy, dx)
+    (64, 80, 80, (128,), 128, False, "silu", True),     # a network-sized layer: many tiles per workgroup, the ring wraps per tile
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv_halo_matches_torch(case):
+    """ccnet_conv_halo (conv_halo.hip): BaseConv k3 s1 p1 and SpaceToDepth + BaseConv k3 (network/model_block.py:37-58, 152-175) with
+    register-streamed weights, against torch fp32 on the same bf16 operands; channel slices with offsets, untouched neighbours."""
+    ops = _ops()
+    B, H, W, cins, cout, s2d, act, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    K = sum(cins)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in cins]
+    cv = 4 * K if s2d else K
+    w = torch.randn(cout, cv, 3, 3, generator=g) / math.sqrt(cv * 9)
+    bias = torch.randn(cout, generator=g) * 0.1
+    pk = ops.PackedHalo(w, bias, DEV)
+    ts = [to_nhwc(x, 1, ldc=x.shape[1] + 16 * (i + 1), coff=8 * (i + 1)) for i, x in enumerate(xs)]
+    Ho, Wo = (H // 2, W // 2) if s2d else (H, W)
+    out = torch.full((B, Ho, Wo, cout + 16), 5.0, dtype=torch.bfloat16, device=DEV)
+    r = torch.randn(B, cout, Ho, Wo, generator=g)
+    tr = to_nhwc(r, 1, ldc=cout + 8, coff=4)
+    ops.conv_halo([ops.sl(t, 8 * (i + 1), c) for i, (t, c) in enumerate(zip(ts, cins))], pk, s2d, B, H, W, ops.sl(out, 8, cout), act,
+                  ops.sl(tr, 4, cout) if use_res else None)
+    torch.cuda.synchronize()
+    xin = torch.cat([q(x, 1) for x in xs], 1)
+    if s2d:   # SpaceToDepth.forward: TL, TR, BL, BR on the channel axis (model_block.py:169-173)
+        xin = torch.cat([xin[..., ::2, ::2], xin[..., ::2, 1::2], xin[..., 1::2, ::2], xin[..., 1::2, 1::2]], 1)
+    actf = {"silu": F.silu, "relu": F.relu, "relu6": F.relu6, "lrelu": lambda t: F.leaky_relu(t, 0.1), "none": lambda t: t}[act]
+    ref = actf(F.conv2d(xin, q(w, 1), bias, 1, 1))
+    if use_res:
+        ref = ref + q(r, 1)
+    assert rel(from_nhwc(out, 8, cout), ref) < tol(1), rel(from_nhwc(out, 8, cout), ref)
+    assert bool((out[..., :8] == 5.0).all()) and bool((out[..., 8 + cout:] == 5.0).all())
+
+
+def test_conv_halo_is_run_to_run_identical_and_close_to_the_lds_weight_kernel():
+    """The same layer on ccnet_conv_halo twice (bit-identical) and on ccnet_conv2d's halo-patch kernel (same rounding points, another
+    accumulation order: within two bf16 ulps of each other relative to the output scale)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(41)
+    B, H, W, C, cout = 16, 40, 40, 128, 128
+    x = (torch.randn(B, H, W, C, generator=g)).to(torch.bfloat16).to(DEV)
+    w = torch.randn(cout, C, 3, 3, generator=g) / math.sqrt(C * 9)
+    bias = torch.randn(cout, generator=g) * 0.1
+    pk, pc = ops.PackedHalo(w, bias, DEV), ops.PackedConv(w, bias, 1, DEV)
+    outs = []
+    for _ in range(3):
+        o = torch.zeros(B, H, W, cout, dtype=torch.bfloat16, device=DEV)
+        ops.conv_halo([ops.sl(x)], pk, False, B, H, W, ops.sl(o), "silu")
+        outs.append(o)
+    ref = torch.zeros(B, H, W, cout, dtype=torch.bfloat16, device=DEV)
+    ops.conv2d([ops.sl(x)], pc, B, H, W, 1, 1, ops.sl(ref), "silu")
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)) and torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
+    assert float((outs[0].float() - ref.float()).abs().max() / ref.float().abs().max()) < 1.6e-2
+
+
 @pytest.mark.parametrize("code", [0, 1])
 def test_conv3x3_two_segments_patch_kernel(code):
     """3x3 over torch.cat([a, b], 1) at a 16-aligned width (MobileViT conv4, network/model_block.py:296-297): the halo-patch
