@@ -161,14 +161,17 @@ def kernel_rooflines(ms, infos, precision, outs, B, S, nc, conf, nms_thr, dev):
     dec = bbox.decode_outputs(outs, [S, S])
     A = dec.shape[1]
     t_dec = _event_ms(lambda: bbox.decode_outputs(outs, [S, S]))
-    out["decode"] = _entry("hbm", 2.0 * B * A * (5 + nc) * 4, t_dec, 1, HBM_PEAK_GBS, "GB/s", {"bytes": 2.0 * B * A * (5 + nc) * 4})
+    dbytes = 2.0 * B * A * (5 + nc) * 4 + B * A * 4.0
+    out["decode"] = _entry("hbm", dbytes, t_dec, 1, HBM_PEAK_GBS, "GB/s", {"bytes": dbytes})
     cand = torch.empty(B, A, 7, dtype=torch.float32, device=dev)
     counts = torch.empty(B, dtype=torch.int32, device=dev)
-    t_fil = _event_ms(lambda: ops.filter_candidates(dec, nc, conf, cand, counts))
+    scores = bbox._scores_of(dec, dec, nc)   # what post_process uses: the per-anchor scores decode left beside the rows
+    t_fil = _event_ms(lambda: ops.filter_candidates(dec, nc, conf, cand, counts, scores))
     cnt = counts.cpu().numpy()
     ncand = int(cnt.sum())
-    fbytes = B * A * (5 + nc) * 4.0 + 28.0 * ncand
-    out["filter"] = _entry("hbm", fbytes, t_fil, 1, HBM_PEAK_GBS, "GB/s", {"bytes": fbytes, "candidates": ncand})
+    fbytes = (B * A * 4.0 + (5 + nc) * 4.0 * ncand if scores is not None else B * A * (5 + nc) * 4.0) + 28.0 * ncand
+    out["filter"] = _entry("hbm", fbytes, t_fil, 1, HBM_PEAK_GBS, "GB/s", {"bytes": fbytes, "candidates": ncand, "reads_scores": scores is not None})
+    out["decode_plus_filter_ms"] = round(t_dec + t_fil, 4)
     nmax = max(int(cnt.max()), 1)
     hw = torch.full((B, 2), S, dtype=torch.int32, device=dev)
     t_nms = _event_ms(lambda: bbox._nms(cand, counts, nmax, nms_thr, hw))

@@ -61,6 +61,9 @@ def lib():
         L.ccnet_transformer_fused.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, C.c_longlong, vp, i32, i32, vp]
         L.ccnet_decode.argtypes = [C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32),
                                    i32, i32, i32, f32, f32, vp, vp]
+        L.ccnet_decode_scored.argtypes = [C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32),
+                                          i32, i32, i32, f32, f32, vp, vp, vp]
+        L.ccnet_filter_scored.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp, vp, vp]
         L.ccnet_filter.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp]
         L.ccnet_filter_workspace_ints.argtypes = [i32, i32]
         L.ccnet_filter_workspace_ints.restype = sz

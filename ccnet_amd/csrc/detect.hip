@@ -26,34 +26,69 @@ struct DecodeP {
     float* out;
 };
 
-// one thread per output ELEMENT (anchor, channel) of image blockIdx.y: with NHWC heads both the load and the store of a wave
-// are contiguous.  Index arithmetic is 32-bit (64-bit divisions made this kernel VALU-bound: 31 us for 47 MB).
-__global__ __launch_bounds__(256) void decode_kernel(const DecodeP p) {
-    // blockIdx.z = level, so every per-level quantity is a scalar; the two index divisions go through a float reciprocal
-    // when every level has fewer than 2^22 elements (two roundings of 2^-24 each keep the product inside its integer cell),
-    // not the ~30-instruction integer sequence
-    const int l = blockIdx.z, b = blockIdx.y;
+// ((raw + grid) * stride) / dim, (exp(raw) * stride) / dim, 1 / (1 + exp(-raw)): same operations on the same operands as
+// bbox.py:39,70-76, arranged as ONE exponential and ONE division per element with selects around them -- a wave holds all
+// channel kinds, and five divergent branches (each with its own IEEE division) made this VALU-bound.  Every per-level quantity
+// is a scalar (blockIdx.z = level); the two index divisions go through a float reciprocal when every level has fewer than 2^22
+// elements (two roundings of 2^-24 each keep the product inside its integer cell), not the ~30-instruction integer sequence.
+// e = element inside the level: r * nch + c
+__device__ __forceinline__ float decode_value(const DecodeP& p, int l, int b, unsigned e) {
     const int wl = p.w[l];
-    const unsigned e = blockIdx.x * 256u + threadIdx.x;      // element inside this level: r * nch + c
-    const unsigned n_l = (unsigned)(p.a0[l + 1] - p.a0[l]) * (unsigned)p.nch;
-    if (e >= n_l) return;
     const int r = p.fast ? (int)(((float)e + 0.5f) * p.rnch) : (int)(e / (unsigned)p.nch);
     const int c = (int)e - r * p.nch;
     const int gy = p.fast ? (int)(((float)r + 0.5f) * p.rw[l]) : r / wl;
     const int gx = r - gy * wl;
-    const unsigned per_img = (unsigned)p.A * (unsigned)p.nch;
     const float raw = p.head[l][(long long)b * p.sb[l] + (long long)r * p.sp[l] + (long long)c * p.sc[l]];
     const float s = p.stride[l];
-    // ((raw + grid) * stride) / dim, (exp(raw) * stride) / dim, 1 / (1 + exp(-raw)): same operations on the same operands as
-    // bbox.py:39,70-76, arranged as ONE exponential and ONE division per element with selects around them -- a wave holds all
-    // channel kinds, and five divergent branches (each with its own IEEE division) made this kernel VALU-bound
     const bool is_xy = c < 2, is_box = c < 4;
     const float ex = expf(is_box ? raw : -raw);
     const float g = (c == 0) ? (float)gx : (float)gy;
     const float num = is_xy ? (raw + g) * s : (is_box ? ex * s : 1.0f);
     const float den = is_box ? ((c & 1) ? p.in_h : p.in_w) : 1.0f + ex;
-    const float v = num / den;
-    p.out[(size_t)b * per_img + (unsigned)p.a0[l] * (unsigned)p.nch + e] = v;
+    return num / den;
+}
+
+// one thread per output ELEMENT (anchor, channel) of image blockIdx.y: with NHWC heads both the load and the store of a wave
+// are contiguous.  Index arithmetic is 32-bit (64-bit divisions made this kernel VALU-bound: 31 us for 47 MB).
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeP p) {
+    const int l = blockIdx.z, b = blockIdx.y;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    const unsigned n_l = (unsigned)(p.a0[l + 1] - p.a0[l]) * (unsigned)p.nch;
+    if (e >= n_l) return;
+    const unsigned per_img = (unsigned)p.A * (unsigned)p.nch;
+    p.out[(size_t)b * per_img + (unsigned)p.a0[l] * (unsigned)p.nch + e] = decode_value(p, l, b, e);
+}
+
+// decode that also leaves, per anchor, the value post_process tests against its threshold (obj * max class probability, the
+// fp32 product filter_keep forms): a block takes 256 anchors of one level, its 256 x nch elements go through the arithmetic
+// above (loads and stores contiguous across the block) and through LDS, from where thread t reads anchor t's row.  The filter
+// then reads 4 bytes per anchor instead of the whole row.
+__global__ __launch_bounds__(256) void decode_scored_kernel(const DecodeP p, float* score) {
+    extern __shared__ float sv[];  // [256][nch]
+    const int l = blockIdx.z, b = blockIdx.y, t = threadIdx.x;
+    const int n_r = p.a0[l + 1] - p.a0[l];
+    const int r0 = blockIdx.x * 256;
+    if (r0 >= n_r) return;
+    const int rows = min(256, n_r - r0);
+    const unsigned nel = (unsigned)rows * (unsigned)p.nch, e0 = (unsigned)r0 * (unsigned)p.nch;
+    float* ob = p.out + (size_t)b * ((unsigned)p.A * (unsigned)p.nch) + (unsigned)p.a0[l] * (unsigned)p.nch + e0;
+#pragma unroll 4
+    for (unsigned i = t; i < nel; i += 256u) {
+        const float v = decode_value(p, l, b, e0 + i);
+        ob[i] = v;
+        sv[i] = v;
+    }
+    __syncthreads();
+    if (t < rows) {
+        const float* r = sv + t * p.nch;
+        const float obj = r[4];
+        float cc = r[5];
+        for (int c = 6; c < p.nch; ++c) {
+            const float v = r[c];
+            if (v > cc) cc = v;
+        }
+        score[(size_t)b * p.A + p.a0[l] + r0 + t] = obj * cc;
+    }
 }
 
 // ---- filter: one block (1024 threads) per image, anchors in order, stable compaction.
@@ -73,7 +108,8 @@ __device__ __forceinline__ bool filter_keep(const float* r, int nc, float conf) 
     return (obj * cc) >= conf;
 }
 // kept anchors per (image, super-chunk): lets filter_kernel run one block per super-chunk on maps with many anchors
-__global__ __launch_bounds__(1024) void filter_count_kernel(const float* pred, int A, int nc, float conf, int nsuper, int* chunk_counts) {
+__global__ __launch_bounds__(1024) void filter_count_kernel(const float* pred, const float* score, int A, int nc, float conf, int nsuper,
+                                                           int* chunk_counts) {
     __shared__ int tot;
     const int b = blockIdx.x, sc = blockIdx.y, t = threadIdx.x;
     const int nch = 5 + nc;
@@ -81,7 +117,8 @@ __global__ __launch_bounds__(1024) void filter_count_kernel(const float* pred, i
     if (t == 0) tot = 0;
     __syncthreads();
     int mine = 0;
-    for (int a = sc * F_SUPER + t; a < min(A, (sc + 1) * F_SUPER); a += 1024) mine += filter_keep(pb + (size_t)a * nch, nc, conf) ? 1 : 0;
+    for (int a = sc * F_SUPER + t; a < min(A, (sc + 1) * F_SUPER); a += 1024)
+        mine += (score ? score[(size_t)b * A + a] >= conf : filter_keep(pb + (size_t)a * nch, nc, conf)) ? 1 : 0;
     const unsigned long long any = __ballot(mine != 0);
     if (any) {
         int v = mine;
@@ -93,9 +130,10 @@ __global__ __launch_bounds__(1024) void filter_count_kernel(const float* pred, i
     if (t == 0) chunk_counts[b * nsuper + sc] = tot;
 }
 // chunk_counts == nullptr: one block per image walks all super-chunks; otherwise block (image, y) does super-chunk y and starts
-// at the sum of the earlier chunks' counts
-__global__ __launch_bounds__(1024) void filter_kernel(const float* pred, int A, int nc, float conf, float* cand, int* counts, int nsuper,
-                                                     const int* chunk_counts) {
+// at the sum of the earlier chunks' counts.  score (may be null): [B][A] values of obj * max class probability from
+// decode_scored_kernel, the same fp32 product the keep test forms from the row.
+__global__ __launch_bounds__(1024) void filter_kernel(const float* pred, const float* score, int A, int nc, float conf, float* cand, int* counts,
+                                                     int nsuper, const int* chunk_counts) {
     __shared__ int cnt[F_IT * 16];
     __shared__ int base_s;
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -117,14 +155,18 @@ __global__ __launch_bounds__(1024) void filter_kernel(const float* pred, int A, 
             const int a = s0 + k * 1024 + t;
             bool keep = false;
             if (a < A) {
-                const float* r = pb + (size_t)a * nch;
-                const float obj = r[4];
-                float cc = r[5];
-                for (int c = 1; c < nc; ++c) {  // the value of the maximum, by the same comparisons as pass 2 (its index is found there)
-                    const float v = r[5 + c];
-                    if (v > cc) cc = v;
+                if (score) {
+                    keep = score[(size_t)b * A + a] >= conf;
+                } else {
+                    const float* r = pb + (size_t)a * nch;
+                    const float obj = r[4];
+                    float cc = r[5];
+                    for (int c = 1; c < nc; ++c) {  // the value of the maximum, by the same comparisons as pass 2 (its index is found there)
+                        const float v = r[5 + c];
+                        if (v > cc) cc = v;
+                    }
+                    keep = (obj * cc) >= conf;
                 }
-                keep = (obj * cc) >= conf;
             }
             flags |= keep ? (1u << k) : 0u;
             const unsigned long long bal = __ballot(keep);
@@ -939,9 +981,11 @@ extern "C" int ccnet_debug_nms_stamps(unsigned long long* out8) {
 }
 #endif
 
-extern "C" int ccnet_decode(const float* const* head_dev, const int64_t* sb, const int64_t* sc, const int64_t* sp, const int32_t* h, const int32_t* w,
-                            int nlev, int B, int nc, float in_h, float in_w, float* out_dev, ccnet_stream stream) {
+extern "C" int ccnet_decode_scored(const float* const* head_dev, const int64_t* sb, const int64_t* sc, const int64_t* sp, const int32_t* h,
+                                   const int32_t* w, int nlev, int B, int nc, float in_h, float in_w, float* out_dev, float* score_dev,
+                                   ccnet_stream stream) {
     CC_REQUIRE(head_dev && sb && sc && sp && h && w && out_dev, "decode: null pointer");
+    CC_REQUIRE(!score_dev || (5 + nc) * 1024 <= 65536, "decode: scores need 5 + nc <= 64 (got nc=%d)", nc);
     CC_REQUIRE(nlev > 0 && nlev <= MAXLEV && B > 0 && nc > 0 && in_h > 0 && in_w > 0, "decode: bad sizes (nlev=%d)", nlev);
     DecodeP p{};
     int A = 0;
@@ -965,13 +1009,22 @@ extern "C" int ccnet_decode(const float* const* head_dev, const int64_t* sb, con
     p.rnch = 1.0f / (float)(5 + nc);
     p.fast = biggest < (1ll << 22) ? 1 : 0;
     const unsigned blocks = (unsigned)((biggest + 255) / 256);
+    const unsigned rblocks = (unsigned)((biggest / (5 + nc) + 255) / 256);
     return ccnet_submit(
-        [p, blocks, B, nlev](hipStream_t st, const float*) -> int {
-            hipLaunchKernelGGL(decode_kernel, dim3(blocks, B, nlev), dim3(256), 0, st, p);
+        [p, blocks, rblocks, B, nlev, score_dev](hipStream_t st, const float*) -> int {
+            if (score_dev)
+                hipLaunchKernelGGL(decode_scored_kernel, dim3(rblocks, B, nlev), dim3(256), (size_t)p.nch * 1024, st, p, score_dev);
+            else
+                hipLaunchKernelGGL(decode_kernel, dim3(blocks, B, nlev), dim3(256), 0, st, p);
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
         stream, CCNET_OP_DECODE, 0.0, 2.0 * B * (double)A * (5 + nc) * 4.0);
+}
+
+extern "C" int ccnet_decode(const float* const* head_dev, const int64_t* sb, const int64_t* sc, const int64_t* sp, const int32_t* h, const int32_t* w,
+                            int nlev, int B, int nc, float in_h, float in_w, float* out_dev, ccnet_stream stream) {
+    return ccnet_decode_scored(head_dev, sb, sc, sp, h, w, nlev, B, nc, in_h, in_w, out_dev, nullptr, stream);
 }
 
 extern "C" size_t ccnet_filter_workspace_ints(int B, int A) {
@@ -979,8 +1032,8 @@ extern "C" size_t ccnet_filter_workspace_ints(int B, int A) {
     return (size_t)B * ((A + F_SUPER - 1) / F_SUPER);
 }
 
-extern "C" int ccnet_filter_ws(const float* pred_dev, int B, int A, int nc, float conf_thres, float* cand_dev, int32_t* counts_dev,
-                               int32_t* workspace_dev, ccnet_stream stream) {
+extern "C" int ccnet_filter_scored(const float* pred_dev, const float* score_dev, int B, int A, int nc, float conf_thres, float* cand_dev,
+                                   int32_t* counts_dev, int32_t* workspace_dev, ccnet_stream stream) {
     CC_REQUIRE(pred_dev && cand_dev && counts_dev, "filter: null pointer");
     CC_REQUIRE(B > 0 && B <= 65535 && A > 0 && nc >= 1 && nc <= 1024, "filter: bad sizes (B=%d A=%d nc=%d)", B, A, nc);
     const int nsuper = (A + F_SUPER - 1) / F_SUPER;
@@ -989,16 +1042,22 @@ extern "C" int ccnet_filter_ws(const float* pred_dev, int B, int A, int nc, floa
     return ccnet_submit(
         [=](hipStream_t st, const float*) -> int {
             if (cc) {
-                hipLaunchKernelGGL(filter_count_kernel, dim3(B, nsuper), dim3(1024), 0, st, pred_dev, A, nc, conf_thres, nsuper, cc);
-                hipLaunchKernelGGL(filter_kernel, dim3(B, nsuper), dim3(1024), 0, st, pred_dev, A, nc, conf_thres, cand_dev, counts_dev, nsuper, cc);
+                hipLaunchKernelGGL(filter_count_kernel, dim3(B, nsuper), dim3(1024), 0, st, pred_dev, score_dev, A, nc, conf_thres, nsuper, cc);
+                hipLaunchKernelGGL(filter_kernel, dim3(B, nsuper), dim3(1024), 0, st, pred_dev, score_dev, A, nc, conf_thres, cand_dev, counts_dev,
+                                   nsuper, cc);
             } else {
-                hipLaunchKernelGGL(filter_kernel, dim3(B), dim3(1024), 0, st, pred_dev, A, nc, conf_thres, cand_dev, counts_dev, nsuper,
+                hipLaunchKernelGGL(filter_kernel, dim3(B), dim3(1024), 0, st, pred_dev, score_dev, A, nc, conf_thres, cand_dev, counts_dev, nsuper,
                                    (const int*)nullptr);
             }
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },
-        stream, CCNET_OP_FILTER, 0.0, (double)B * A * (5 + nc) * 4.0);
+        stream, CCNET_OP_FILTER, 0.0, (double)B * A * (score_dev ? 1 : 5 + nc) * 4.0);
+}
+
+extern "C" int ccnet_filter_ws(const float* pred_dev, int B, int A, int nc, float conf_thres, float* cand_dev, int32_t* counts_dev,
+                               int32_t* workspace_dev, ccnet_stream stream) {
+    return ccnet_filter_scored(pred_dev, nullptr, B, A, nc, conf_thres, cand_dev, counts_dev, workspace_dev, stream);
 }
 
 extern "C" int ccnet_filter(const float* pred_dev, int B, int A, int nc, float conf_thres, float* cand_dev, int32_t* counts_dev,

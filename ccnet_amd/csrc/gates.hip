@@ -1,11 +1,16 @@
 // Attention gates: CBAM (channel + spatial), ECA, and the ASFF softmax fusion.  All HBM-bound elementwise /
-// reduction kernels over NHWC; reductions are two-stage and atomic-free, so results are run-to-run identical.
+// reduction kernels over NHWC; reductions are two-stage with a fixed order, so results are run-to-run identical.
 //
 // CBAM passes (dependency-forced 3 reads + 1 write of x):
 //   1 pool_partial : per (image, pixel chunk) sum and max per channel            -> scratch
-//   2 cbam_mlp     : finish avg/max, shared MLP, sigmoid                          -> ca[B][C]
+//   2 cbam_mlp     : finish avg/max, shared MLP, sigmoid (one block per image)    -> ca[B][C]
 //   3 cbam_stats   : per pixel mean_c / max_c of x*ca                             -> stats[B][H][W][2]
 //   4 cbam_apply   : sa = sigmoid(conv kxk(stats)); out = x*ca*sa
+// ECA: pool_partial + eca_gate + scale.
+// Pass 2 was tried inside pass 1 (round 3: the block that finishes an image last, found through a per-image agent-scope counter,
+// runs the MLP).  Publishing the partials across XCDs (sc1 stores, the wait for them, the counter's round trip) holds every
+// pooling block's CU slot about twice as long: pool 22 -> 42 us at 80x80x128 x 64 images, against the 11 us launch it saves.
+// Measured slower in total (0.217 against 0.192 ms for the three CBAMs of `net`), so the gate stays a launch of its own.
 #include <math.h>
 #include "common.h"
 
@@ -29,64 +34,70 @@ GateScratch gate_scratch(int B, int H, int W, int C) {
     return s;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void pool_partial_kernel(const unsigned char* in, int ldc, int coff, int C, int HW, int nchunk, float* partial) {
-    __shared__ float red[2][256][8];
-    const int G = C / 8;
-    const int b = blockIdx.y, chunk = blockIdx.x;
-    const int p0 = chunk * POOL_CHUNK;
-    const int p1 = min(HW, p0 + POOL_CHUNK);
-    const int t = threadIdx.x;
-    for (int g0 = 0; g0 < G; g0 += 256) {
-        const int TG = min(G - g0, 256);
-        const int PL = 256 / TG;
-        const int g = g0 + t % TG, pl = t / TG;
-        float s[8], m[8];
+// avg[c] (and mx[c] when given) of one image from its chunk partials [chunk][2][C].  A thread owns a (sum | max, 4 channels)
+// pair; with few pairs the chunks are split over nt / pairs thread groups and combined in group order through tmp (4 * nt
+// floats, may be null: no split).  The summation order depends on C and nt only.
+__device__ inline void finish_pool(const float* pb, int nchunk, int C, int HW, float* avg, float* mx, float* tmp, int t, int nt) {
+    const int Q = C / 4, pairs = mx ? 2 * Q : Q;
+    const int parts = (tmp != nullptr && 2 * pairs <= nt) ? nt / pairs : 1;
+    for (int pr0 = 0; pr0 < pairs; pr0 += nt) {   // one pass unless there are more pairs than threads
+        const int pr = parts > 1 ? t % pairs : pr0 + t;
+        const int part = parts > 1 ? t / pairs : 0;
+        const bool live = pr < pairs && part < parts;
+        const int kind = live ? pr / Q : 0, quad = live ? pr - kind * Q : 0;
+        float4 acc = kind ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (live) {
+            // 8 chunk rows in flight (the index is clamped so that no load sits behind a branch; surplus rows are not used)
+            for (int k0 = part; k0 < nchunk; k0 += 8 * parts) {
+                float4 v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] = 0.0f; m[e] = -INFINITY; }
-        if (pl < PL) {
-            for (int p = p0 + pl; p < p1; p += PL) {
-                float v[8];
-                Chan8<T>::load(in + (((size_t)b * HW + p) * ldc + coff + g * 8) * sizeof(T), v);
+                for (int u = 0; u < 8; ++u) {
+                    const int k = min(k0 + u * parts, nchunk - 1);
+                    v[u] = *(const float4*)(pb + (size_t)(k * 2 + kind) * C + quad * 4);
+                }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { s[e] += v[e]; m[e] = fmaxf(m[e], v[e]); }
+                for (int u = 0; u < 8; ++u) {
+                    if (k0 + u * parts < nchunk) {
+                        if (kind) {
+                            acc.x = fmaxf(acc.x, v[u].x); acc.y = fmaxf(acc.y, v[u].y); acc.z = fmaxf(acc.z, v[u].z); acc.w = fmaxf(acc.w, v[u].w);
+                        } else {
+                            acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+                        }
+                    }
+                }
             }
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { red[0][t][e] = s[e]; red[1][t][e] = m[e]; }
-        __syncthreads();
-        if (t < TG) {
-            for (int q = 1; q < PL; ++q)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { s[e] += red[0][t + q * TG][e]; m[e] = fmaxf(m[e], red[1][t + q * TG][e]); }
-            float* dst = partial + (((size_t)b * nchunk + chunk) * 2) * C + g * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { dst[e] = s[e]; dst[C + e] = m[e]; }
+        if (parts > 1) {
+            if (live) *(float4*)(tmp + (size_t)(part * pairs + pr) * 4) = acc;
+            __syncthreads();
+            if (t < pairs) {
+                acc = *(const float4*)(tmp + (size_t)t * 4);
+                for (int q = 1; q < parts; ++q) {
+                    const float4 v = *(const float4*)(tmp + (size_t)(q * pairs + t) * 4);
+                    if (kind) {
+                        acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y); acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w);
+                    } else {
+                        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                    }
+                }
+            }
         }
-        __syncthreads();
+        if (live && part == 0) {
+            float* dst = kind ? mx + quad * 4 : avg + quad * 4;
+            if (kind) { dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w; }
+            else { dst[0] = acc.x / (float)HW; dst[1] = acc.y / (float)HW; dst[2] = acc.z / (float)HW; dst[3] = acc.w / (float)HW; }
+        }
     }
+    __syncthreads();
 }
 
-// one block per image; dynamic LDS: avg[C] max[C] hid[2*Cr]
-__global__ __launch_bounds__(1024) void cbam_mlp_kernel(const float* partial, int nchunk, int C, int Cr, int HW, const float* fc1, const float* fc2,
-                                                       float* ca) {
-    extern __shared__ float sm[];
+// CBAM channel gate of one image: ca = sigmoid(fc2 relu(fc1 avg) + fc2 relu(fc1 max)).  sm: avg[C] max[C] hid[2*Cr]
+__device__ inline void cbam_mlp_body(const float* pb, int nchunk, int C, int Cr, int HW, const float* fc1, const float* fc2, float* ca_b, float* sm,
+                                     float* tmp, int t, int nt) {
     float* avg = sm;
     float* mx = sm + C;
     float* hid = sm + 2 * C;
-    const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;  // 256 or 1024 threads: one pass over the hidden units at C = 512
-    for (int c = t; c < C; c += nt) {
-        float s = 0.0f, m = -INFINITY;
-#pragma unroll 8
-        for (int k = 0; k < nchunk; ++k) {
-            const float* src = partial + (((size_t)b * nchunk + k) * 2) * C;
-            s += src[c];
-            m = fmaxf(m, src[C + c]);
-        }
-        avg[c] = s / (float)HW;
-        mx[c] = m;
-    }
-    __syncthreads();
+    finish_pool(pb, nchunk, C, HW, avg, mx, tmp, t, nt);
     const int lane = t & 63, wave = t >> 6;
     // hidden unit j (< Cr: on the average, >= Cr: on the maximum); 8 units per wave pass so that 8 rows of fc1 are in flight
     for (int j0 = wave * 8; j0 < 2 * Cr; j0 += (nt >> 6) * 8) {
@@ -127,98 +138,194 @@ __global__ __launch_bounds__(1024) void cbam_mlp_kernel(const float* partial, in
         } else {
             for (int j = 0; j < Cr; ++j) { a = fmaf(wr[j], hid[j], a); m = fmaf(wr[j], hid[Cr + j], m); }
         }
-        ca[(size_t)b * C + c] = sigmoidf_(a + m);
+        ca_b[c] = sigmoidf_(a + m);
     }
 }
 
-// LP lanes cooperate on one pixel (LP = power of two >= C/8, at most 64)
+// ECA gate of one image: avg over pixels -> 3-tap conv over the channel axis (zero padded) -> sigmoid.  sm: avg[C]
+__device__ inline void eca_gate_body(const float* pb, int nchunk, int C, int HW, const float* w3, float* gate_b, float* sm, float* tmp, int t, int nt) {
+    float* avg = sm;
+    finish_pool(pb, nchunk, C, HW, avg, nullptr, tmp, t, nt);
+    for (int c = t; c < C; c += nt) {
+        float l = c > 0 ? avg[c - 1] : 0.0f, r = c + 1 < C ? avg[c + 1] : 0.0f;
+        gate_b[c] = sigmoidf_(w3[0] * l + w3[1] * avg[c] + w3[2] * r);
+    }
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void cbam_stats_kernel(const unsigned char* in, int ldc, int coff, int C, int HW, long long npix, int LP,
-                                                         const float* ca, float* stats) {
+__global__ __launch_bounds__(256) void pool_partial_kernel(const unsigned char* in, int ldc, int coff, int C, int HW, int nchunk, float* partial) {
+    __shared__ float red[2][256][8];
     const int G = C / 8;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int p0 = chunk * POOL_CHUNK;
+    const int p1 = min(HW, p0 + POOL_CHUNK);
     const int t = threadIdx.x;
-    const int sub = t % LP;
-    const long long pix = ((long long)blockIdx.x * 256 + t) / LP;
-    const bool live = pix < npix;
-    const int b = live ? (int)(pix / HW) : 0;
-    float s = 0.0f, m = -INFINITY;
-    if (live) {
-        for (int g = sub; g < G; g += LP) {
-            float v[8];
-            Chan8<T>::load(in + ((size_t)pix * ldc + coff + g * 8) * sizeof(T), v);
-            const float* cg = ca + (size_t)b * C + g * 8;
+    for (int g0 = 0; g0 < G; g0 += 256) {
+        const int TG = min(G - g0, 256);
+        const int PL = 256 / TG;
+        const int g = g0 + t % TG, pl = t / TG;
+        float s[8], m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.0f; m[e] = -INFINITY; }
+        if (pl < PL) {
+            const unsigned char* src = in + (((size_t)b * HW) * ldc + coff + g * 8) * sizeof(T);
+            // 4 pixels in flight per thread (clamped index: no load behind a branch; a surplus pixel is loaded and not used)
+            for (int pb = p0 + pl; pb < p1; pb += 4 * PL) {
+                float v[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Chan8<T>::load(src + (size_t)min(pb + u * PL, p1 - 1) * ldc * sizeof(T), v[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (pb + u * PL < p1) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { s[e] += v[u][e]; m[e] = fmaxf(m[e], v[u][e]); }
+                    }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[0][t][e] = s[e]; red[1][t][e] = m[e]; }
+        __syncthreads();
+        // every thread finishes output values (sum | max, channel): PL reads each, in pixel-lane order
+        const int nout = TG * 8;
+        float* dst = partial + (((size_t)b * nchunk + chunk) * 2) * C + g0 * 8;
+        for (int o = t; o < 2 * nout; o += 256) {
+            const int kind = o >= nout ? 1 : 0, rem = o - kind * nout;
+            const float* r = &red[kind][0][0] + rem;
+            float acc = r[0];
+            if (kind) {
+                for (int q = 1; q < PL; ++q) acc = fmaxf(acc, r[q * nout]);
+            } else {
+                for (int q = 1; q < PL; ++q) acc += r[q * nout];
+            }
+            dst[kind * C + rem] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// one block per image; dynamic LDS: avg[C] max[C] hid[2*Cr] | 4 * blockDim floats for the split chunk reduction
+__global__ __launch_bounds__(1024) void cbam_mlp_kernel(const float* partial, int nchunk, int C, int Cr, int HW, const float* fc1, const float* fc2,
+                                                       float* ca) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x;
+    // the weights do not depend on the pooling result: one load per 128-byte line starts them on their way into L2 / L1 while the
+    // partials are reduced (every stage of this kernel is a chain of cold misses otherwise: 17 us at C = 512)
+    float warm = 0.0f;
+    for (int i = threadIdx.x * 32; i < Cr * C; i += blockDim.x * 32) warm += fc1[i] + fc2[i];
+    cbam_mlp_body(partial + (size_t)b * nchunk * 2 * C, nchunk, C, Cr, HW, fc1, fc2, ca + (size_t)b * C, sm, sm + ((2 * C + 2 * Cr + 3) & ~3), threadIdx.x,
+                  blockDim.x);
+    asm volatile("" ::"v"(warm));
+}
+
+__global__ __launch_bounds__(256) void eca_gate_kernel(const float* partial, int nchunk, int C, int HW, const float* w3, float* gate) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x;
+    eca_gate_body(partial + (size_t)b * nchunk * 2 * C, nchunk, C, HW, w3, gate + (size_t)b * C, sm, sm + C, threadIdx.x, 256);
+}
+
+// LP lanes cooperate on one pixel (LP = power of two >= C/8, at most 64); a thread works on GP_PIX pixels of image blockIdx.y
+// at once (pixel slot + u * slots), so that it has GP_PIX 16-byte loads in flight and reads its channels' gate once.
+// One load per thread left the reads at 3.9 TB/s; the 64-bit index divisions of the first version cost as much as the loads.
+constexpr int GP_PIX = 4;
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_stats_kernel(const unsigned char* in, int ldc, int coff, int C, int HW, int lps, const float* ca,
+                                                         float* stats) {
+    const int G = C / 8, LP = 1 << lps, slots = 256 >> lps;
+    const int t = threadIdx.x, b = blockIdx.y;
+    const int sub = t & (LP - 1), slot = t >> lps;
+    const int pbase = blockIdx.x * (slots * GP_PIX) + slot;
+    const unsigned char* src = in + (((size_t)b * HW) * ldc + coff) * sizeof(T);
+    float s[GP_PIX], m[GP_PIX];
+#pragma unroll
+    for (int u = 0; u < GP_PIX; ++u) { s[u] = 0.0f; m[u] = -INFINITY; }
+    for (int g = sub; g < G; g += LP) {
+        float v[GP_PIX][8];
+#pragma unroll
+        for (int u = 0; u < GP_PIX; ++u) Chan8<T>::load(src + ((size_t)min(pbase + u * slots, HW - 1) * ldc + g * 8) * sizeof(T), v[u]);
+        const float4 c0 = *(const float4*)(ca + (size_t)b * C + g * 8), c1 = *(const float4*)(ca + (size_t)b * C + g * 8 + 4);
+        const float cg[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (int u = 0; u < GP_PIX; ++u)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float x = v[e] * cg[e];
-                s += x;
-                m = fmaxf(m, x);
+                const float x = v[u][e] * cg[e];
+                s[u] += x;
+                m[u] = fmaxf(m[u], x);
             }
+    }
+    for (int o = LP >> 1; o > 0; o >>= 1) {
+#pragma unroll
+        for (int u = 0; u < GP_PIX; ++u) {
+            s[u] += __shfl_xor(s[u], o, 64);
+            m[u] = fmaxf(m[u], __shfl_xor(m[u], o, 64));
+        }
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int u = 0; u < GP_PIX; ++u) {
+            const int pix = pbase + u * slots;
+            if (pix < HW) *(float2*)(stats + ((size_t)b * HW + pix) * 2) = make_float2(s[u] / (float)C, m[u]);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_apply_kernel(const unsigned char* in, int ldc, int coff, int C, int H, int W, int lps, const float* ca,
+                                                         const float* stats, const float* wk, int k, unsigned char* out, int out_ldc,
+                                                         int out_coff) {
+    const int G = C / 8, LP = 1 << lps, slots = 256 >> lps, HW = H * W;
+    const int t = threadIdx.x, b = blockIdx.y;
+    const int sub = t & (LP - 1), slot = t >> lps;
+    const int pbase = blockIdx.x * (slots * GP_PIX) + slot;
+    int py[GP_PIX], px[GP_PIX];
+    float a[GP_PIX];
+#pragma unroll
+    for (int u = 0; u < GP_PIX; ++u) {
+        const int pix = min(pbase + u * slots, HW - 1);
+        py[u] = pix / W;
+        px[u] = pix - py[u] * W;
+        a[u] = 0.0f;
+    }
+    // spatial gate: the k x k taps of the (mean, max) planes are spread over the LP lanes of a pixel; a tap's weights and offsets
+    // are found once for the thread's GP_PIX pixels; a tap outside the image reads pixel 0 with zero weights (no branch)
+    const float2* sp = (const float2*)stats + (size_t)b * HW;
+    const int pad = k / 2, kk = k * k;
+    for (int tap = sub; tap < kk; tap += LP) {
+        const int ky = tap / k, kx = tap - ky * k;
+        const float wa = wk[tap], wm = wk[kk + tap];
+#pragma unroll
+        for (int u = 0; u < GP_PIX; ++u) {
+            const int iy = py[u] + ky - pad, ix = px[u] + kx - pad;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const float2 sv = sp[ok ? iy * W + ix : 0];
+            a[u] = fmaf(ok ? wa : 0.0f, sv.x, a[u]);
+            a[u] = fmaf(ok ? wm : 0.0f, sv.y, a[u]);
         }
     }
     for (int o = LP >> 1; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o, 64);
-        m = fmaxf(m, __shfl_xor(m, o, 64));
+#pragma unroll
+        for (int u = 0; u < GP_PIX; ++u) a[u] += __shfl_xor(a[u], o, 64);
     }
-    if (live && sub == 0) {
-        stats[pix * 2] = s / (float)C;
-        stats[pix * 2 + 1] = m;
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void cbam_apply_kernel(const unsigned char* in, int ldc, int coff, int C, int H, int W, long long npix, int LP,
-                                                         const float* ca, const float* stats, const float* wk, int k, unsigned char* out,
-                                                         int out_ldc, int out_coff) {
-    const int G = C / 8;
-    const int t = threadIdx.x;
-    const int sub = t % LP;
-    const long long pix = ((long long)blockIdx.x * 256 + t) / LP;
-    const bool live = pix < npix;
-    const int HW = H * W;
-    float a = 0.0f;
-    int b = 0;
-    if (live) {
-        b = (int)(pix / HW);
-        const int r = (int)(pix - (long long)b * HW);
-        const int y = r / W, x = r - y * W;
-        const int pad = k / 2, kk = k * k;
-        for (int tap = sub; tap < kk; tap += LP) {
-            const int ky = tap / k, kx = tap - ky * k;
-            const int iy = y + ky - pad, ix = x + kx - pad;
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                const float* sp = stats + (((size_t)b * H + iy) * W + ix) * 2;
-                a = fmaf(wk[tap], sp[0], a);
-                a = fmaf(wk[kk + tap], sp[1], a);
+    float sa[GP_PIX];
+#pragma unroll
+    for (int u = 0; u < GP_PIX; ++u) sa[u] = sigmoidf_(a[u]);
+    const unsigned char* src = in + (((size_t)b * HW) * ldc + coff) * sizeof(T);
+    unsigned char* dst = out + (((size_t)b * HW) * out_ldc + out_coff) * sizeof(T);
+    for (int g = sub; g < G; g += LP) {
+        float v[GP_PIX][8];
+#pragma unroll
+        for (int u = 0; u < GP_PIX; ++u) Chan8<T>::load(src + ((size_t)min(pbase + u * slots, HW - 1) * ldc + g * 8) * sizeof(T), v[u]);
+        const float4 c0 = *(const float4*)(ca + (size_t)b * C + g * 8), c1 = *(const float4*)(ca + (size_t)b * C + g * 8 + 4);
+        const float cg[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (int u = 0; u < GP_PIX; ++u) {
+            const int pix = pbase + u * slots;
+            if (pix < HW) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[u][e] = (v[u][e] * cg[e]) * sa[u];
+                Chan8<T>::store(dst + ((size_t)pix * out_ldc + g * 8) * sizeof(T), v[u]);
             }
         }
-    }
-    for (int o = LP >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    if (!live) return;
-    const float sa = sigmoidf_(a);
-    for (int g = sub; g < G; g += LP) {
-        float v[8];
-        Chan8<T>::load(in + ((size_t)pix * ldc + coff + g * 8) * sizeof(T), v);
-        const float* cg = ca + (size_t)b * C + g * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] * cg[e]) * sa;
-        Chan8<T>::store(out + ((size_t)pix * out_ldc + out_coff + g * 8) * sizeof(T), v);
-    }
-}
-
-// ECA gate: avg over pixels -> 3-tap conv over the channel axis (zero padded) -> sigmoid
-__global__ __launch_bounds__(256) void eca_gate_kernel(const float* partial, int nchunk, int C, int HW, const float* w3, float* gate) {
-    extern __shared__ float avg[];
-    const int b = blockIdx.x, t = threadIdx.x;
-    for (int c = t; c < C; c += 256) {
-        float s = 0.0f;
-#pragma unroll 8
-        for (int k = 0; k < nchunk; ++k) s += partial[(((size_t)b * nchunk + k) * 2) * C + c];
-        avg[c] = s / (float)HW;
-    }
-    __syncthreads();
-    for (int c = t; c < C; c += 256) {
-        float l = c > 0 ? avg[c - 1] : 0.0f, r = c + 1 < C ? avg[c + 1] : 0.0f;
-        gate[(size_t)b * C + c] = sigmoidf_(w3[0] * l + w3[1] * avg[c] + w3[2] * r);
     }
 }
 
@@ -297,13 +404,16 @@ extern "C" int ccnet_cbam(ccnet_slice in, int dtype, int B, int H, int W, const 
                           float* scratch_dev, ccnet_slice out, ccnet_stream stream) {
     CC_REQUIRE(cc_dtype_ok(dtype) && slice8_ok(in, dtype) && slice8_ok(out, dtype) && in.C == out.C && in.shift == 0 && out.shift == 0,
                "cbam: bad slices");
-    CC_REQUIRE(fc1 && fc2 && w7 && scratch_dev && Cr > 0 && (k7 == 7 || k7 == 3), "cbam: bad weights (Cr=%d k=%d)", Cr, k7);
+    CC_REQUIRE(fc1 && fc2 && w7 && scratch_dev && ((uintptr_t)scratch_dev & 15) == 0 && Cr > 0 && (k7 == 7 || k7 == 3),
+               "cbam: bad weights or scratch not 16-byte aligned (Cr=%d k=%d)", Cr, k7);
     CC_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && (long long)B * H * W < (1ll << 31), "cbam: bad geometry");
     const int C = in.C, HW = H * W;
     const GateScratch gs = gate_scratch(B, H, W, C);
-    const long long npix = (long long)B * HW;
     const int LP = lanes_per_pixel(C);
-    const unsigned pblocks = (unsigned)((npix * LP + 255) / 256);
+    int lps = 0;
+    while ((1 << lps) < LP) ++lps;
+    const int ppb = (256 / LP) * GP_PIX;  // pixels per block
+    const dim3 pgrid((unsigned)((HW + ppb - 1) / ppb), (unsigned)B);
     return ccnet_submit(
         [=](hipStream_t st, const float*) -> int {
             float* partial = scratch_dev + gs.partial;
@@ -311,20 +421,20 @@ extern "C" int ccnet_cbam(ccnet_slice in, int dtype, int B, int H, int W, const 
             float* stats = scratch_dev + gs.stats;
             const unsigned char* ip = (const unsigned char*)in.ptr;
             unsigned char* op = (unsigned char*)out.ptr;
-            size_t mlp_lds = (size_t)(2 * C + 2 * Cr) * sizeof(float);
             const int mlp_threads = 2 * Cr >= 64 ? 1024 : 256;  // 8 hidden units per wave pass
+            const size_t mlp_lds = (size_t)(((2 * C + 2 * Cr + 3) & ~3) + 4 * mlp_threads) * sizeof(float);
             if (dtype == CCNET_BF16) {
                 hipLaunchKernelGGL(pool_partial_kernel<__bf16>, dim3(gs.nchunk, B), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, gs.nchunk, partial);
                 hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(mlp_threads), mlp_lds, st, partial, gs.nchunk, C, Cr, HW, fc1, fc2, ca);
-                hipLaunchKernelGGL(cbam_stats_kernel<__bf16>, dim3(pblocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, npix, LP, ca, stats);
-                hipLaunchKernelGGL(cbam_apply_kernel<__bf16>, dim3(pblocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, H, W, npix, LP, ca, stats, w7,
-                                   k7, op, out.ldc, out.coff);
+                hipLaunchKernelGGL(cbam_stats_kernel<__bf16>, pgrid, dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, lps, ca, stats);
+                hipLaunchKernelGGL(cbam_apply_kernel<__bf16>, pgrid, dim3(256), 0, st, ip, in.ldc, in.coff, C, H, W, lps, ca, stats, w7, k7, op,
+                                   out.ldc, out.coff);
             } else {
                 hipLaunchKernelGGL(pool_partial_kernel<float>, dim3(gs.nchunk, B), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, gs.nchunk, partial);
                 hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(mlp_threads), mlp_lds, st, partial, gs.nchunk, C, Cr, HW, fc1, fc2, ca);
-                hipLaunchKernelGGL(cbam_stats_kernel<float>, dim3(pblocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, npix, LP, ca, stats);
-                hipLaunchKernelGGL(cbam_apply_kernel<float>, dim3(pblocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, H, W, npix, LP, ca, stats, w7,
-                                   k7, op, out.ldc, out.coff);
+                hipLaunchKernelGGL(cbam_stats_kernel<float>, pgrid, dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, lps, ca, stats);
+                hipLaunchKernelGGL(cbam_apply_kernel<float>, pgrid, dim3(256), 0, st, ip, in.ldc, in.coff, C, H, W, lps, ca, stats, w7, k7, op,
+                                   out.ldc, out.coff);
             }
             CC_LAUNCH_CHECK();
             return CCNET_OK;
@@ -336,7 +446,7 @@ extern "C" int ccnet_eca(ccnet_slice in, int dtype, int B, int H, int W, const f
                          ccnet_stream stream) {
     CC_REQUIRE(cc_dtype_ok(dtype) && slice8_ok(in, dtype) && slice8_ok(out, dtype) && in.C == out.C && in.shift == 0 && out.shift == 0,
                "eca: bad slices");
-    CC_REQUIRE(w3 && scratch_dev, "eca: null pointer");
+    CC_REQUIRE(w3 && scratch_dev && ((uintptr_t)scratch_dev & 15) == 0, "eca: null pointer or scratch not 16-byte aligned");
     CC_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && (long long)B * H * W < (1ll << 31), "eca: bad geometry");
     const int C = in.C, HW = H * W;
     const GateScratch gs = gate_scratch(B, H, W, C);
@@ -350,11 +460,11 @@ extern "C" int ccnet_eca(ccnet_slice in, int dtype, int B, int H, int W, const f
             unsigned char* op = (unsigned char*)out.ptr;
             if (dtype == CCNET_BF16) {
                 hipLaunchKernelGGL(pool_partial_kernel<__bf16>, dim3(gs.nchunk, B), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, gs.nchunk, partial);
-                hipLaunchKernelGGL(eca_gate_kernel, dim3(B), dim3(256), C * sizeof(float), st, partial, gs.nchunk, C, HW, w3, gate);
+                hipLaunchKernelGGL(eca_gate_kernel, dim3(B), dim3(256), (C + 1024) * sizeof(float), st, partial, gs.nchunk, C, HW, w3, gate);
                 hipLaunchKernelGGL(scale_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, total, gate, op, out.ldc, out.coff);
             } else {
                 hipLaunchKernelGGL(pool_partial_kernel<float>, dim3(gs.nchunk, B), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, gs.nchunk, partial);
-                hipLaunchKernelGGL(eca_gate_kernel, dim3(B), dim3(256), C * sizeof(float), st, partial, gs.nchunk, C, HW, w3, gate);
+                hipLaunchKernelGGL(eca_gate_kernel, dim3(B), dim3(256), (C + 1024) * sizeof(float), st, partial, gs.nchunk, C, HW, w3, gate);
                 hipLaunchKernelGGL(scale_kernel<float>, dim3(blocks), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, total, gate, op, out.ldc, out.coff);
             }
             CC_LAUNCH_CHECK();

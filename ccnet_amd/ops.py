@@ -279,9 +279,13 @@ def transformer_fused(src, src_ld, out, out_ld, S, N, stream_w, fpw, params, n_e
                                         params.data_ptr(), n_enc, n_dec, stream_ptr()))
 
 
-def decode(heads, nc, in_h, in_w, out):
+DECODE_SCORE_MAX_NCH = 64
+
+
+def decode(heads, nc, in_h, in_w, out, scores=None):
     """heads: list of fp32 CUDA tensors viewed as (B, 5+nc, h, w) with arbitrary strides over (b, c) and a uniform
-    pixel stride (NCHW contiguous or an NHWC buffer permuted to NCHW)."""
+    pixel stride (NCHW contiguous or an NHWC buffer permuted to NCHW).  scores (optional, (B, A) fp32, 5 + nc <= 64): filled
+    with obj * max class probability per anchor, which filter_candidates can read instead of the rows."""
     n = len(heads)
     B = heads[0].shape[0]
     ptrs = (C.c_void_p * n)(*[h.data_ptr() for h in heads])
@@ -298,17 +302,17 @@ def decode(heads, nc, in_h, in_w, out):
             raise ValueError("decode: head %d rows are not uniformly strided" % i)
         sb[i], sc[i], sp[i] = st[0], st[1], st[3]
         hh[i], ww[i] = h.shape[2], h.shape[3]
-    check(lib().ccnet_decode(ptrs, sb, sc, sp, hh, ww, n, B, nc, float(in_h), float(in_w), out.data_ptr(), stream_ptr()))
+    check(lib().ccnet_decode_scored(ptrs, sb, sc, sp, hh, ww, n, B, nc, float(in_h), float(in_w), out.data_ptr(),
+                                    scores.data_ptr() if scores is not None else None, stream_ptr()))
 
 
-def filter_candidates(pred, nc, conf, cand, counts):
+def filter_candidates(pred, nc, conf, cand, counts, scores=None):
     B, A, _ = pred.shape
     nws = int(lib().ccnet_filter_workspace_ints(B, A))
-    if nws:  # many anchors per image: one workgroup per 32768 anchors after a counting pass
-        ws = torch.empty(nws, dtype=torch.int32, device=pred.device)
-        check(lib().ccnet_filter_ws(pred.data_ptr(), B, A, nc, float(np.float32(conf)), cand.data_ptr(), counts.data_ptr(), ws.data_ptr(), stream_ptr()))
-        return
-    check(lib().ccnet_filter(pred.data_ptr(), B, A, nc, float(np.float32(conf)), cand.data_ptr(), counts.data_ptr(), stream_ptr()))
+    # many anchors per image: one workgroup per 32768 anchors after a counting pass
+    ws = torch.empty(nws, dtype=torch.int32, device=pred.device) if nws else None
+    check(lib().ccnet_filter_scored(pred.data_ptr(), scores.data_ptr() if scores is not None else None, B, A, nc, float(np.float32(conf)),
+                                    cand.data_ptr(), counts.data_ptr(), ws.data_ptr() if nws else None, stream_ptr()))
 
 
 def nms_workspace_bytes(B, nmax):

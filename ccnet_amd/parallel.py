@@ -145,7 +145,7 @@ def sharded_post_process(prediction, num_classes, input_shape, image_info, conf_
             cnt = both[n_rows + bmax:].view(torch.int32)   # candidate counts, int32 bit patterns in the fp32 buffer
             if B and A:
                 if first:
-                    ops.filter_candidates(pred, num_classes, conf_thres, buf["cand"], cnt[:B])
+                    ops.filter_candidates(pred, num_classes, conf_thres, buf["cand"], cnt[:B], bbox._scores_of(prediction, pred, num_classes))
                     cand, first = buf["cand"], False
                 else:
                     cnt[:B].copy_(cnt0)

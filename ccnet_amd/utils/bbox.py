@@ -58,9 +58,28 @@ def decode_outputs(outputs, input_shape):
     A = sum(int(h.shape[2]) * int(h.shape[3]) for h in heads)
     out = torch.empty(B, A, nch, dtype=torch.float32, device=heads[0].device)
     if B * A:
+        # the same kernel leaves obj * max class probability per anchor beside the rows; post_process reads those 4 bytes per
+        # anchor for its threshold test as long as the tensor it is given is this one, unmodified (_scores_of)
+        scores = torch.empty(B, A, dtype=torch.float32, device=out.device) if 5 < nch <= ops.DECODE_SCORE_MAX_NCH else None
         with torch.cuda.device(out.device):  # launches go to the tensors' device, whatever the caller's current device is
-            ops.decode(heads, nch - 5, input_shape[0], input_shape[1], out)
+            ops.decode(heads, nch - 5, input_shape[0], input_shape[1], out, scores)
+        if scores is not None:
+            out._ccnet_scores = (scores, out._version, out.data_ptr())
     return out
+
+
+def _scores_of(prediction, pred, num_classes):
+    """The per-anchor scores decode_outputs left beside `prediction`, or None: only when `pred` (what the kernels will read) IS
+    that tensor, no in-place operation has touched it since (torch's version counter) and the class count is the decoded one."""
+    side = getattr(prediction, "_ccnet_scores", None)
+    if side is None or pred is not prediction:
+        return None
+    scores, version, ptr = side
+    if prediction._version != version or prediction.data_ptr() != ptr or prediction.shape[2] != 5 + num_classes:
+        return None
+    if scores.shape != prediction.shape[:2] or scores.device != prediction.device:
+        return None
+    return scores
 
 
 _nmax_guess = {}
@@ -70,8 +89,9 @@ class PendingDetections:
     """Detections of one batch whose kernels and device->host copy have been submitted (post_process_async).  `result()` waits
     for the copy and returns what post_process returns.  Holding the object keeps every buffer the kernels use alive."""
 
-    def __init__(self, pred, num_classes, conf_thres, nms_thres, image_hw):
+    def __init__(self, pred, num_classes, conf_thres, nms_thres, image_hw, scores=None):
         self._done = None
+        self.scores = scores
         B, A, _ = pred.shape
         dev = pred.device
         self.B, self.A, self.key = B, A, (B, A, str(dev))
@@ -82,7 +102,7 @@ class PendingDetections:
         if nmax is None:
             # first call for this (B, A, device): wait for the counts, then run NMS with the exact maximum
             self.counts = torch.empty(B, dtype=torch.int32, device=dev)
-            ops.filter_candidates(pred, num_classes, conf_thres, self.cand, self.counts)
+            ops.filter_candidates(pred, num_classes, conf_thres, self.cand, self.counts, scores)
             self.nmax = min(max(int(self.counts.cpu().max()), 1), A)
             self.both = _result_buffer(B, self.nmax, dev)
             self.both[B * self.nmax * 7 + B:].view(torch.int32).copy_(self.counts)
@@ -91,7 +111,7 @@ class PendingDetections:
             self.both = _result_buffer(B, self.nmax, dev)
             # the filter kernel writes its counts straight into the result buffer
             self.counts = self.both[B * self.nmax * 7 + B:].view(torch.int32)
-            ops.filter_candidates(pred, num_classes, conf_thres, self.cand, self.counts)
+            ops.filter_candidates(pred, num_classes, conf_thres, self.cand, self.counts, scores)
         self._submit()
 
     def _submit(self):
@@ -118,7 +138,7 @@ class PendingDetections:
                 det = host[:B * nmax * 7].reshape(B, nmax, 7)
                 nk = host[B * nmax * 7:B * nmax * 7 + B].view(np.int32)
                 self._done = [det[b, :nk[b]].copy() for b in range(B)]
-                self.pred = self.cand = self.both = self.counts = self.host = None
+                self.pred = self.cand = self.both = self.counts = self.host = self.scores = None
                 return self._done
             # an image had more candidates than the rows NMS was given (the kernels cut, never overrun): once more, exact
             with torch.cuda.device(self.cand.device):
@@ -181,7 +201,7 @@ def post_process_async(prediction, num_classes, input_shape, image_info, conf_th
     pred = prediction.float().contiguous()
     hw = _image_hw(tuple((int(image_info[i][2]), int(image_info[i][1])) for i in range(B)), pred.device)
     with torch.cuda.device(pred.device):
-        return PendingDetections(pred, num_classes, conf_thres, nms_thres, hw)
+        return PendingDetections(pred, num_classes, conf_thres, nms_thres, hw, _scores_of(prediction, pred, num_classes))
 
 
 class _Ready:

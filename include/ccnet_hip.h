@@ -130,7 +130,8 @@ int ccnet_maxpool3x3s2(ccnet_slice in, int dtype, int B, int H, int W, ccnet_sli
 
 /* ---- attention gates -------------------------------------------------------------------------------------
  * CBAM.forward (network/attention_block.py:19-22): x*ca then *sa.  fc1: fp32 [C/r][C], fc2: fp32 [C][C/r],
- * w7: fp32 [2][k][k] (avg plane first), k = 7 or 3.  scratch_dev: fp32, ccnet_gate_scratch_floats(B,H,W,C) floats. */
+ * w7: fp32 [2][k][k] (avg plane first), k = 7 or 3.  scratch_dev: fp32, 16-byte aligned, ccnet_gate_scratch_floats(B,H,W,C)
+ * floats; calls sharing a scratch must not overlap. */
 size_t ccnet_gate_scratch_floats(int B, int H, int W, int C);
 int ccnet_cbam(ccnet_slice in, int dtype, int B, int H, int W, const float* fc1, const float* fc2, int Cr,
                const float* w7, int k7, float* scratch_dev, ccnet_slice out, ccnet_stream stream);
@@ -172,6 +173,12 @@ int ccnet_transformer_fused(const void* src, int src_ld, void* out, int out_ld, 
 int ccnet_decode(const float* const* head_dev, const int64_t* sb, const int64_t* sc, const int64_t* sp, const int32_t* h,
                  const int32_t* w, int nlev, int B, int nc, float in_h, float in_w, float* out_dev, ccnet_stream stream);
 
+/* The same, and per anchor the value post_process compares with its threshold: score_dev fp32 [B][A] = obj * max class
+ * probability (the fp32 product of utils/bbox.py:104-107).  Needs 5 + nc <= 64.  score_dev NULL = ccnet_decode. */
+int ccnet_decode_scored(const float* const* head_dev, const int64_t* sb, const int64_t* sc, const int64_t* sp,
+                        const int32_t* h, const int32_t* w, int nlev, int B, int nc, float in_h, float in_w, float* out_dev,
+                        float* score_dev, ccnet_stream stream);
+
 /* post_process part 1 (utils/bbox.py:98-130): cxcywh->xyxy, class max (first index on ties), keep
  * obj*cls >= conf_thres (fp32 compare), order-preserving compaction.
  * cand_dev: fp32 [B][A][7] rows [x1,y1,x2,y2,obj,cls_conf,cls_id]; counts_dev: int32 [B]. */
@@ -183,6 +190,10 @@ int ccnet_filter(const float* pred_dev, int B, int A, int nc, float conf_thres, 
 size_t ccnet_filter_workspace_ints(int B, int A);
 int ccnet_filter_ws(const float* pred_dev, int B, int A, int nc, float conf_thres, float* cand_dev, int32_t* counts_dev,
                     int32_t* workspace_dev, ccnet_stream stream);
+/* ccnet_filter_ws whose keep test reads score_dev (from ccnet_decode_scored on the same pred_dev: 4 bytes per anchor instead of
+ * the row); rows are read for kept anchors only.  Results are identical.  score_dev NULL = ccnet_filter_ws. */
+int ccnet_filter_scored(const float* pred_dev, const float* score_dev, int B, int A, int nc, float conf_thres, float* cand_dev,
+                        int32_t* counts_dev, int32_t* workspace_dev, ccnet_stream stream);
 /* post_process part 2 (utils/bbox.py:133-158): torchvision.ops.boxes.batched_nms (0.9.0 coordinate trick; third party,
  * see DESIGN.md) + gather + rescale to image pixels.  Above 256 rows per image the work is partitioned by class group
  * (classes whose offset boxes cannot meet), which leaves every bit of the global algorithm's result unchanged.

@@ -427,7 +427,7 @@ def _cbam_ref(x, fc1, fc2, w7):
 
 
 @pytest.mark.parametrize("code", [0, 1])
-@pytest.mark.parametrize("Cc,H,W", [(128, 28, 28), (512, 7, 7), (64, 40, 36), (24, 5, 5)])
+@pytest.mark.parametrize("Cc,H,W", [(128, 28, 28), (512, 7, 7), (64, 40, 36), (24, 5, 5), (1024, 6, 6)])
 def test_cbam(code, Cc, H, W):
     ops = _ops()
     g = torch.Generator().manual_seed(23)
@@ -444,6 +444,42 @@ def test_cbam(code, Cc, H, W):
     torch.cuda.synchronize()
     ref = _cbam_ref(q(x, code), fc1, fc2, w7)
     assert rel(from_nhwc(out, 0, Cc), ref) < (2e-5 if code == 0 else 6e-3)
+    # the same scratch again: identical output
+    out2 = torch.zeros(B, H, W, Cc, dtype=tdt(code), device=DEV)
+    ops.cbam(ops.sl(xin), code, B, H, W, d1, d2, d7, scratch, ops.sl(out2))
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
+
+
+def test_gates_are_run_to_run_identical_and_batch_independent_on_a_large_map():
+    """80x80x128, 64 images: 50 pooling blocks per image, the chunk partials summed in a fixed order split over thread groups;
+    the output must not change between launches, and an image alone must equal the image in the batch."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, Cc, H, W = 64, 128, 80, 80
+    x = torch.randn(B, H, W, Cc, generator=g).to(torch.bfloat16).to(DEV)
+    fc1 = (torch.randn(8, Cc, generator=g) * 0.2).to(DEV)
+    fc2 = (torch.randn(Cc, 8, generator=g) * 0.5).to(DEV)
+    w7 = (torch.randn(2, 7, 7, generator=g) * 0.3).to(DEV)
+    w3 = torch.randn(3, generator=g).to(DEV)
+    scratch = torch.zeros(ops.gate_scratch_floats(B, H, W, Cc), dtype=torch.float32, device=DEV)
+    outs = []
+    for _ in range(4):
+        o = torch.zeros(B, H, W, Cc, dtype=torch.bfloat16, device=DEV)
+        ops.cbam(ops.sl(x), 1, B, H, W, fc1, fc2, w7, scratch, ops.sl(o))
+        e = torch.zeros(B, H, W, Cc, dtype=torch.bfloat16, device=DEV)
+        ops.eca(ops.sl(x), 1, B, H, W, w3, scratch, ops.sl(e))
+        outs.append((o, e))
+    torch.cuda.synchronize()
+    for o, e in outs[1:]:
+        assert torch.equal(o, outs[0][0]) and torch.equal(e, outs[0][1])
+    # image 5 alone equals image 5 in the batch
+    o1 = torch.zeros(1, H, W, Cc, dtype=torch.bfloat16, device=DEV)
+    ops.cbam(ops.sl(x[5:6].contiguous()), 1, 1, H, W, fc1, fc2, w7, scratch, ops.sl(o1))
+    torch.cuda.synchronize()
+    assert torch.equal(o1[0], outs[0][0][5])
+    gate = torch.sigmoid(F.conv1d(x.float().mean((1, 2))[:, None], w3.view(1, 1, 3), None, 1, 1))[:, 0]
+    assert rel(outs[0][1].float(), x.float() * gate[:, None, None, :]) < 6e-3
 
 
 @pytest.mark.parametrize("code", [0, 1])
@@ -549,6 +585,53 @@ def test_decode_matches_oracle_layouts():
         torch.cuda.synchronize()
         # fp32 tolerance: expf/sigmoid differ from ATen's vectorised CPU versions by a few ulp
         assert torch.allclose(out.cpu(), ref, rtol=2e-6, atol=1e-7), float((out.cpu() - ref).abs().max())
+
+
+def test_scored_decode_and_filter_equal_the_plain_ones():
+    """ccnet_decode_scored writes the same rows as ccnet_decode bit for bit plus obj * max class per anchor; the filter reading
+    those scores keeps the same rows in the same order.  bbox.decode_outputs hands the scores to post_process only while the
+    tensor is the one it returned, unmodified."""
+    from ccnet_amd.utils import bbox
+    ops = _ops()
+    g = torch.Generator().manual_seed(44)
+    for B, nc, hw in ((3, 6, [(20, 32), (10, 16), (5, 8)]), (2, 1, [(7, 9)]), (2, 59, [(33, 17), (3, 3)])):
+        heads = [(torch.randn(B, 5 + nc, h, w, generator=g) * 2).to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2) for h, w in hw]
+        A = sum(h * w for h, w in hw)
+        plain = torch.zeros(B, A, 5 + nc, device=DEV)
+        both = torch.zeros(B, A, 5 + nc, device=DEV)
+        scores = torch.zeros(B, A, device=DEV)
+        ops.decode(heads, nc, 160, 256, plain)
+        ops.decode(heads, nc, 160, 256, both, scores)
+        torch.cuda.synchronize()
+        assert torch.equal(plain, both)
+        assert torch.equal(scores, plain[..., 4] * plain[..., 5:].max(-1)[0])
+        for conf in (0.05, 0.5):
+            c0, n0 = torch.zeros(B, A, 7, device=DEV), torch.zeros(B, dtype=torch.int32, device=DEV)
+            c1, n1 = torch.zeros(B, A, 7, device=DEV), torch.zeros(B, dtype=torch.int32, device=DEV)
+            ops.filter_candidates(plain, nc, conf, c0, n0)
+            ops.filter_candidates(plain, nc, conf, c1, n1, scores)
+            torch.cuda.synchronize()
+            assert torch.equal(n0, n1) and int(n0.sum()) > 0
+            for b in range(B):
+                assert torch.equal(c0[b, :int(n0[b])], c1[b, :int(n1[b])])
+    with pytest.raises(Exception):   # 5 + nc > 64: no scores
+        ops.decode([torch.zeros(1, 85, 4, 4, device=DEV)], 80, 64, 64, torch.zeros(1, 16, 85, device=DEV), torch.zeros(1, 16, device=DEV))
+    dec = bbox.decode_outputs(heads, [160, 256])
+    assert bbox._scores_of(dec, dec, 59) is not None and bbox._scores_of(dec, dec, 6) is None
+    assert bbox._scores_of(dec.clone(), dec.clone(), 59) is None
+    info = [[i, 320, 240] for i in range(2)]
+    want = bbox.post_process(dec.clone(), 59, [160, 256], info, 0.3, 0.5)      # rows path
+    got = bbox.post_process(dec, 59, [160, 256], info, 0.3, 0.5)               # scores path
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    dec[..., 4] *= 0.5                                                         # modified in place: the scores are stale and must not be used
+    assert bbox._scores_of(dec, dec, 59) is None
+    want = bbox.post_process(dec.clone(), 59, [160, 256], info, 0.3, 0.5)
+    got = bbox.post_process(dec, 59, [160, 256], info, 0.3, 0.5)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    big = bbox.decode_outputs([torch.randn(1, 85, 4, 4, device=DEV)], [64, 64])   # 80 classes: plain decode, no scores
+    assert getattr(big, "_ccnet_scores", None) is None
 
 
 def _run_post(pred, nc, conf, thr, info):
