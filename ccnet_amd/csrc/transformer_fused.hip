@@ -129,12 +129,23 @@ __device__ __forceinline__ f32x2 pair2(float v) {
 
 // Four waves.  Wave w owns output columns [64w, 64w+64) of every 256-wide GEMM, columns [32w, 32w+32) of each per-head
 // Q/K/V projection, and query tile w (16 queries) of the attention core.
-__global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP p) {
-    extern __shared__ __align__(16) unsigned char sm[];
-    const int t = threadIdx.x, lane = t & 63, lane0 = lane;
+#ifndef TF_PAIR
+#define TF_PAIR 0
+#endif
+// TF_PAIR=1 (experiment, off): a workgroup is EIGHT waves = two positions side by side (waves 0-3 and 4-7, 80 KB of LDS each,
+// one workgroup per CU).  Nothing is shared between the halves but the barriers: waves w and w + 4 consume the same weight
+// stream in step, in the hope that the second request for a fragment meets the first one's line in the CU's L1.  Measured on
+// one box: 0.889 ms against 0.884 ms for two independent workgroups per CU -- no gain, so the default stays unpaired.
+__global__ __launch_bounds__(NW * 64 * (TF_PAIR ? 2 : 1), TF_PAIR ? 1 : 2) void transformer_fused_kernel(const TfP p) {
+    extern __shared__ __align__(16) unsigned char sm_all[];
+    const int half = TF_PAIR ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+    unsigned char* sm = sm_all + half * LDS_BYTES;
+    const int t = threadIdx.x & 255, lane = t & 63, lane0 = lane;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int fr = lane & 15, fq = lane >> 4, fr0 = fr, fq0 = fq;
-    const int n = blockIdx.x;
+    // an odd position count leaves the last workgroup's second half without a position: it repeats the first half's (same
+    // values to the same addresses) so that it takes part in every barrier
+    const int n = TF_PAIR ? min((int)blockIdx.x * 2 + half, p.N - 1) : (int)blockIdx.x;
     unsigned char* X = sm + OFF_X;
     unsigned char* RA = sm + OFF_A;
     unsigned char* RB = sm + OFF_B;
@@ -428,6 +439,11 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
         to_z(zacc, ob);
     };
 
+    // FFN in eight chunks of 128 hidden channels: linear1 chunk (wave w owns 32 of its columns) -> ReLU -> [64][128] tile in
+    // region A or B (alternating, so one barrier per chunk is enough: a wave that has passed chunk c's barrier has finished
+    // reading the tile of chunk c-1, which is the buffer chunk c+1 writes) -> that K slice of linear2 into the 64-column
+    // accumulator the wave keeps across the chunks.  (Chunks of 256 held 64 + 64 accumulator registers beside the ring and
+    // spilled ring slots; the k order of linear2 is the same, results are bit-identical.)
     auto ffn = [&]() __attribute__((always_inline)) {
         const int fr = opaque(fr0), fq = opaque(fq0);
         const float* b1 = pp;
@@ -435,28 +451,30 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
         pp += FF + E;
         f32x4 acc2[4][4];
         zero<4>(acc2);
-        for (int c = 0; c < FF / 256; ++c) {
-            float4 hb[4];
+#pragma unroll 2
+        for (int c = 0; c < FF / 128; ++c) {
+            unsigned char* HT = (c & 1) ? RB : RA;
+            float4 hb[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) hb[j] = *(const float4*)(b1 + c * 256 + wave * 64 + j * 16 + fq * 4);
-            f32x4 acc1[4][4];
-            zero<4>(acc1);
-            mm<4, 8, 512>(acc1, X, ring, wp, loff, lx);
+            for (int j = 0; j < 2; ++j) hb[j] = *(const float4*)(b1 + c * 128 + wave * 32 + j * 16 + fq * 4);
+            f32x4 acc1[4][2];
+            zero<2>(acc1);
+            mm<2, 8, 512>(acc1, X, ring, wp, loff, lx);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n0 = wave * 64 + j * 16 + fq * 4;  // column inside the chunk
+            for (int j = 0; j < 2; ++j) {
+                const int n0 = wave * 32 + j * 16 + fq * 4;  // column inside the chunk
                 const float4 bv = hb[j];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     float v[4] = {fmaxf(acc1[mt][j][0] + bv.x, 0.f), fmaxf(acc1[mt][j][1] + bv.y, 0.f), fmaxf(acc1[mt][j][2] + bv.z, 0.f),
                                   fmaxf(acc1[mt][j][3] + bv.w, 0.f)};
-                    *(uint2*)(RA + xoff(mt * 16 + fr, n0 >> 3) + (n0 & 4) * 2) = pack4(v);
+                    *(uint2*)(HT + qoff(mt * 16 + fr, n0 >> 3) + (n0 & 4) * 2) = pack4(v);
                 }
             }
             TSYNC();
-            mm<4, 8, 512>(acc2, RA, ring, wp, loff, lx);
-            TSYNC();  // before the next chunk overwrites the hidden tile (or the LayerNorm table region C)
+            mm<4, 4, 256>(acc2, HT, ring, wp, loff, lq);
         }
+        TSYNC();  // region A / B (and the LayerNorm table in C) are free again
         float4 b2v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) b2v[j] = *(const float4*)(b2 + wave * 64 + j * 16 + fq * 4);
@@ -493,8 +511,8 @@ __global__ __launch_bounds__(NW * 64, 2) void transformer_fused_kernel(const TfP
 
 extern "C" int ccnet_transformer_fused_frags(int n_enc, int n_dec, long long* frags_per_wave, long long* param_floats) {
     CC_REQUIRE(n_enc >= 0 && n_dec >= 0 && frags_per_wave && param_floats, "transformer_fused_frags: bad arguments");
-    // per wave (4 waves): attention = 2 heads x (3 projections x 16 + out_proj slice 16), FFN = 4 chunks x (32 + 32)
-    const long long attn = 2 * (3 * 16 + 16), ffn = (FF / 256) * 64;
+    // per wave (4 waves): attention = 2 heads x (3 projections x 16 + out_proj slice 16), FFN = 8 chunks x (16 + 16)
+    const long long attn = 2 * (3 * 16 + 16), ffn = (FF / 128) * 32;
     *frags_per_wave = (long long)n_enc * (attn + ffn) + (long long)n_dec * (2 * attn + ffn);
     const long long pa = 4 * E, pl = 2 * E, pf = FF + E;
     *param_floats = (long long)n_enc * (pa + pl + pf + pl) + pl + (long long)n_dec * (2 * (pa + pl) + pf + pl) + pl;
@@ -526,10 +544,14 @@ extern "C" int ccnet_transformer_fused(const void* src, int src_ld, void* out, i
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
             if (!attr_set[dev]) {
-                CC_HIP(hipFuncSetAttribute((const void*)transformer_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                CC_HIP(hipFuncSetAttribute((const void*)transformer_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           LDS_BYTES * (TF_PAIR ? 2 : 1)));
                 attr_set[dev] = true;
             }
-            hipLaunchKernelGGL(transformer_fused_kernel, dim3(p.N), dim3(NW * 64), LDS_BYTES, st, p);
+            if (TF_PAIR)
+                hipLaunchKernelGGL(transformer_fused_kernel, dim3((p.N + 1) / 2), dim3(NW * 128), LDS_BYTES * 2, st, p);
+            else
+                hipLaunchKernelGGL(transformer_fused_kernel, dim3(p.N), dim3(NW * 64), LDS_BYTES, st, p);
             CC_LAUNCH_CHECK();
             return CCNET_OK;
         },

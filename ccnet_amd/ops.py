@@ -201,8 +201,8 @@ def pack_transformer(sd, prefix, n_enc, n_dec, device):
     """Weight stream and parameter vector of ccnet_transformer_fused for the nn.Transformer under `prefix`
     (d_model 256, 2 heads, FF 1024).  The order below IS the kernel's program order (transformer_fused.hip), for each of
     its 4 waves: per attention block, per head, the Q/K/V projections (wave w owns 32 columns of each), then out_proj (wave w
-    owns 64 output columns); per FFN, four 256-wide hidden
-    chunks, linear1 chunk then the matching K slice of linear2.  Inside a GEMM call fragments run k-tile major, n-tile minor."""
+    owns 64 output columns); per FFN, eight 128-wide hidden
+    chunks, linear1 chunk (wave w owns 32 of its columns) then the matching K slice of linear2.  Inside a GEMM call fragments run k-tile major, n-tile minor."""
     E, FF, NW, RING = 256, 1024, 4, 16
     f64 = lambda t: t.detach().to(torch.float64).cpu()
 
@@ -230,13 +230,13 @@ def pack_transformer(sd, prefix, n_enc, n_dec, device):
         per_wave = []
         for w in range(NW):
             seq = []
-            for c in range(FF // 256):
+            for c in range(FF // 128):
                 for kt in range(8):
+                    for j in range(2):
+                        seq.append(f1[c * 8 + w * 2 + j, kt])
+                for kt in range(4):
                     for j in range(4):
-                        seq.append(f1[c * 16 + w * 4 + j, kt])
-                for kt in range(8):
-                    for j in range(4):
-                        seq.append(f2[w * 4 + j, c * 8 + kt])
+                        seq.append(f2[w * 4 + j, c * 4 + kt])
             per_wave.append(torch.stack(seq))
         return per_wave, [f64(sd[q + ".linear1.bias"]), f64(sd[q + ".linear2.bias"])]
 
