@@ -451,14 +451,12 @@ extern "C" int ccnet_conv_halo(const ccnet_slice* in, int nseg, int s2d, int B, 
     const double flops = 2.0 * (double)M * Cout * 9.0 * cvirt;
     const double bytes = ((double)B * H * W * ctot + (double)Cout * 9.0 * cvirt) * 2.0 + (double)M * Cout * (2.0 + (residual.ptr ? 2.0 : 0.0));
     const bool s2 = s2d != 0;
-    // 128 output channels per workgroup where that still gives every workgroup slot (2 per CU on 256 CUs) a tile; 64 on small
-    // maps (twice the tiles: 256 -> 256 @ 20x20 x 32 images 36 -> 28 us).  Both shapes accumulate a pixel's sum in the same
-    // order, so the choice -- which depends on the batch size -- does not change a bit of the result (tests/test_ops_gpu.py).
-    // CCNET_HALO_BN=64|128 forces one (measurement and that test).
+    // 128 output channels per workgroup wherever Cout allows.  A rule that switched to 64-channel tiles when the 128-channel ones
+    // leave workgroup slots empty looked better layer by layer in a microbenchmark and cost 5 % of the MFMA-bound group inside
+    // the network (same-box A/B, scripts/ab_env.sh: 2.35 against 2.23 ms per forward).  Both shapes accumulate a pixel's sum in the
+    // same order, so the choice never changes a bit of the result.  CCNET_HALO_BN=64 forces the small tile (measurement, test).
     static const char* force_bn = getenv("CCNET_HALO_BN");
-    int bn = ((Cout % 128) == 0 && (long long)p.ntiles * (Cout / 128) >= 512) ? 128 : 64;
-    if (force_bn && force_bn[0] == '6') bn = 64;
-    if (force_bn && force_bn[0] == '1' && (Cout % 128) == 0) bn = 128;
+    const int bn = ((Cout % 128) == 0 && !(force_bn && force_bn[0] == '6')) ? 128 : 64;
     return ccnet_submit(
         [p, lin, s2, bn](hipStream_t st, const float*) -> int { return bn == 128 ? launch_halo<128>(p, lin, s2, st) : launch_halo<64>(p, lin, s2, st); },
         stream, CCNET_OP_CONV, flops, bytes);

@@ -460,5 +460,5 @@ extern "C" int ccnet_csp_fused(const ccnet_slice* in, int nseg, int B, int H, in
             if (wlds) return sc ? launch_csp<2, true, true>(p, st, wbytes) : launch_csp<2, false, true>(p, st, wbytes);
             return sc ? launch_csp<2, true, false>(p, st, wbytes) : launch_csp<2, false, false>(p, st, wbytes);
         },
-        stream, CCNET_OP_CONV, flops, bytes);
+        stream, CCNET_OP_CSP, flops, bytes);
 }

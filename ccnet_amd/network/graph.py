@@ -258,9 +258,11 @@ class Compiler:
             return None
         # The choice must not depend on the batch size: the two kernels round alike but accumulate in different orders, and image i of
         # a batch has to equal image i run alone bit for bit (tests/test_forward_gpu.py: batch independence; sharded == unsharded).
-        # 256-position tiles leave the 20 x 20 maps with too few workgroups unless the layer has four column blocks (measured at 64
-        # images: 256 -> 256 is 40 us here and 39 us on ccnet_conv2d's 128-position tiles, 1024 -> 512 is 235 against 241).
-        if Ho * Wo <= 400 and cout < 512 and os.environ.get("CCNET_HALO_SMALL_MAPS", "0") == "0":
+        # The 20 x 20 maps with fewer than four column blocks were kept on ccnet_conv2d's 128-position tiles at first (a per-layer
+        # microbenchmark had them equal); inside the network the halo kernel is the faster one there too (same-box A/B,
+        # scripts/ab_env.sh: step 4.706 -> 4.643 ms for `net` at 64 images, 2.263 -> 2.255 for `net_deploy` at 32).
+        # CCNET_HALO_SMALL_MAPS=0 brings the old rule back.
+        if Ho * Wo <= 400 and cout < 512 and os.environ.get("CCNET_HALO_SMALL_MAPS", "1") == "0":
             return None
         pk = ops.PackedHalo(w, b, self.dev)
         self.keep.append(pk)
@@ -310,9 +312,11 @@ class Compiler:
         w2, b2 = self.folded(p + ".conv2")
         h = w1.shape[0]
         x0 = ins[0]
-        # hidden 32 (160^2 at 640: 392 -> 233 us at bs64) and hidden 64 on one input tensor (dark3.1 at 80^2: 198 -> 164 us); with two
-        # input segments (C3_p3) hidden 64 only equals the five launches, so it is not taken (CCNET_FUSED_CSP_ALL=1 forces it)
-        wide_ok = h == 64 and (len(ins) == 1 or os.environ.get("CCNET_FUSED_CSP_ALL", "0") == "1")
+        # hidden 32 (160^2 at 640: 392 -> 233 us at bs64) and hidden 64 (dark3.1 at 80^2: 198 -> 164 us).  With two input segments
+        # (C3_p3) hidden 64 measured equal to the five launches when timed alone and was left out in round 2; inside the network it
+        # wins (same-box A/B, scripts/ab_env.sh: step -0.6 ... -2 % on `net`, `net_deploy` and `net_small_target`), so it is taken
+        # too.  CCNET_FUSED_CSP_ALL=0 brings the round-2 rule back.
+        wide_ok = h == 64 and (len(ins) == 1 or os.environ.get("CCNET_FUSED_CSP_ALL", "1") != "0")
         if (self.dtype == BF16 and n == 1 and not amff and (h == 32 or wide_ok) and self.act == "silu" and x0.H % 8 == 0 and x0.W % 16 == 0
                 and all(t.C % 64 == 0 and t.shift <= 1 for t in ins) and self.sd[p + ".conv3.conv.weight"].shape[0] == 2 * h
                 and os.environ.get("CCNET_NO_FUSED_CSP", "0") == "0"):

@@ -276,7 +276,8 @@ void ccnet_plan_destroy(ccnet_plan* plan);
 enum {
     CCNET_OP_OTHER = 0, CCNET_OP_CONV = 1, CCNET_OP_STEM = 2, CCNET_OP_DWCONV = 3, CCNET_OP_SPPF = 4, CCNET_OP_MAXPOOL = 5,
     CCNET_OP_CBAM = 6, CCNET_OP_ECA = 7, CCNET_OP_ASFF = 8, CCNET_OP_LAYERNORM = 9, CCNET_OP_ATTENTION = 10,
-    CCNET_OP_DECODE = 11, CCNET_OP_FILTER = 12, CCNET_OP_NMS = 13, CCNET_OP_TRANSFORMER = 14
+    CCNET_OP_DECODE = 11, CCNET_OP_FILTER = 12, CCNET_OP_NMS = 13, CCNET_OP_TRANSFORMER = 14,
+    CCNET_OP_CSP = 15 /* a whole CSPLayer in one launch (ccnet_csp_fused) */
 };
 int ccnet_plan_op_info(const ccnet_plan* plan, int i, int* kind, double* flops, double* bytes);
 int ccnet_plan_run_timed(const ccnet_plan* plan, const float* x_dev, ccnet_stream stream, float* ms_per_op);

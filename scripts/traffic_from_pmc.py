@@ -10,10 +10,11 @@ prof, log, out = sys.argv[1:4]
 ops = []
 op_ms = []
 for line in open(log):
-    m = re.match(r"\s+op\s+(\d+)\s+conv\s+([\d.]+) ms\s+[\d.]+ TF/s\s+[\d.]+ GB/s\s+([\d.]+) GF\s+([\d.]+) MB", line)
+    m = re.match(r"\s+op\s+(\d+)\s+(conv|csp_fused)\s+([\d.]+) ms\s+[\d.]+ TF/s\s+[\d.]+ GB/s\s+([\d.]+) GF\s+([\d.]+) MB", line)
     if m:
-        ops.append((float(m.group(3)) * 1e9, float(m.group(4)) * 1e6))
-        op_ms.append(float(m.group(2)))
+        # a fused CSP launch is priced against HBM like bench.py does: its flops are zeroed for the split at the ridge
+        ops.append((0.0 if m.group(2) == "csp_fused" else float(m.group(4)) * 1e9, float(m.group(5)) * 1e6))
+        op_ms.append(float(m.group(3)))
 n = len(ops)
 
 def per_dispatch(path):

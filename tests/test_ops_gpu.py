@@ -311,7 +311,7 @@ def test_conv_halo_is_run_to_run_identical_and_close_to_the_lds_weight_kernel():
     torch.cuda.synchronize()
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)) and torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
     assert float((outs[0].float() - ref.float()).abs().max() / ref.float().abs().max()) < 1.6e-2
-    # 16 images take 64-channel workgroup tiles (fewer tiles than workgroup slots), 128 images 128-channel ones: same bits
+    # the same images inside a batch eight times as large (other tile count per workgroup, other rounds): same bits
     xb = x.repeat(8, 1, 1, 1)
     ob = torch.zeros(8 * B, H, W, cout, dtype=torch.bfloat16, device=DEV)
     ops.conv_halo([ops.sl(xb)], pk, False, 8 * B, H, W, ops.sl(ob), "silu")
