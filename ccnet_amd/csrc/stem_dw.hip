@@ -41,9 +41,16 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : 1) void stem_kernel(const StemP 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int fr = lane & 15, fq = lane >> 4;
 
+    // PAIR8 (two n-tiles, 2-byte outputs -- the s-width stem): LDS row j*16 + q*4 + r holds output channel q*8 + j*4 + r, so that a
+    // lane's registers of the two tiles are the 8 consecutive channels q*8 .. q*8+7 of its pixel: one 16-byte store per pixel, and a
+    // wave's store instruction covers 16 consecutive pixels x 64 bytes = 1 KB of whole lines (separately the two tiles wrote 32-byte
+    // pieces at a 64-byte stride: 13 M write requests of 32 bytes for 419 MB)
+    constexpr bool PAIR8 = NT == 2 && sizeof(OutT) == 2;
+    auto chan_of = [](int n) { return PAIR8 ? ((n >> 2) & 3) * 8 + (n >> 4) * 4 + (n & 3) : n; };
     for (int e = t; e < CP * KS; e += 256) {
-        int n = e / KS;
-        wl[e] = (T)(n < p.Cout ? p.w[e] : 0.0f);
+        const int n = e / KS, k = e - n * KS;
+        const int c = chan_of(n);
+        wl[e] = (T)(c < p.Cout ? p.w[c * KS + k] : 0.0f);
     }
     // columns PW..PWP-1 of every patch row are never fetched but are read under the zero-weight kx slots 6,7
     static_assert(PW + 4 == PWP, "pad columns");
@@ -53,7 +60,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : 1) void stem_kernel(const StemP 
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int n = j * 16 + fq * 4 + r;
+            const int n = chan_of(j * 16 + fq * 4 + r);
             breg[j][r] = n < p.Cout ? p.bias[n] : 0.0f;
         }
 
@@ -164,6 +171,23 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : 1) void stem_kernel(const StemP 
             const int oy = oy0 + 2 * wave + (mt >> 1), ox = ox0 + (mt & 1) * 16 + fr;
             if (oy >= p.Ho || ox >= p.Wo) continue;
             const size_t pix = ((size_t)b * p.Ho + oy) * p.Wo + ox;
+            if constexpr (PAIR8) {
+                if (fq * 8 >= p.Cout) continue;
+                uint32_t pk[4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = acc[mt][j][r] + breg[j][r];
+                        v[r] = p.act == CCNET_ACT_SILU ? act_fn<CCNET_ACT_SILU>(a) : apply_act(a, p.act);
+                    }
+                    pk[2 * j] = pack_bf16x2(v[0], v[1]);
+                    pk[2 * j + 1] = pack_bf16x2(v[2], v[3]);
+                }
+                *(uint4*)(p.out + (pix * p.out_ldc + p.out_coff + fq * 8) * 2) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                continue;
+            }
             unsigned char* orow = p.out + (pix * p.out_ldc + p.out_coff + fq * 4) * sizeof(OutT);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
