@@ -396,7 +396,7 @@ def main():
         t_pp, _ = timed(lambda: bbox.post_process(dec, 6, [S, S], info, args.conf, args.nms))
         print("phases: forward %.3f ms  decode %.3f ms  post_process %.3f ms" % (t_fwd, t_dec, t_pp), file=sys.stderr)
         names = {0: "other", 1: "conv", 2: "stem", 3: "dwconv", 4: "sppf", 5: "maxpool", 6: "cbam", 7: "eca", 8: "asff", 9: "layernorm",
-                 10: "attention", 14: "transformer"}
+                 10: "attention", 14: "transformer", 15: "csp_fused"}
         agg = {}
         for m, (k, f, b) in zip(ms, infos):
             a = agg.setdefault(k, [0.0, 0.0, 0.0, 0])
