@@ -272,9 +272,34 @@ class Compiler:
         ops.conv_halo([t.sl() for t in ins], pk, s2d, self.B, x0.H, x0.W, out.sl(), act, None if residual is None else residual.sl())
         return out
 
+    def conv1x1_pw(self, w, b, ins, act, out=None, residual=None):
+        """1x1 s1 on ccnet_conv_pw (pixels in LDS, weights streamed into registers) when the shape qualifies, else None.  Its results
+        are bit-identical to ccnet_conv2d's, so the rule below is a speed matter only: K >= 256 (CCNET_PW_MIN_K), where the implicit
+        GEMM's short K loop is latency-bound; the K = 128 layers stay on the streaming kernel."""
+        if self.dtype != BF16 or os.environ.get("CCNET_NO_PW_CONV", "0") != "0":
+            return None
+        x0 = ins[0]
+        cout, cin = w.shape[0], w.shape[1]
+        if cin < int(os.environ.get("CCNET_PW_MIN_K", "256")):
+            return None
+        probe_out = out.sl() if out is not None else _lib.Slice(None, cout, 0, cout, 0)
+        if not ops.conv_pw_ok(self.dtype, None, [t.sl() for t in ins], cout, probe_out, None if residual is None else residual.sl()):
+            return None
+        pk = ops.PackedPw(w, b, self.dev)
+        self.keep.append(pk)
+        if out is None:
+            out = self.new(cout, x0.H, x0.W)
+        assert (out.H, out.W, out.C) == (x0.H, x0.W, cout), "conv output slice mismatch"
+        ops.conv_pw([t.sl() for t in ins], pk, self.B, x0.H, x0.W, out.sl(), act, None if residual is None else residual.sl())
+        return out
+
     def conv_w(self, w, b, ins, stride, pad, act, out=None, residual=None, out_dtype=None):
         if w.shape[-1] == 3 and w.shape[-2] == 3 and stride == 1 and pad == 1 and out_dtype is None:
             got = self.conv3x3_halo(w, b, ins, False, act, out, residual)
+            if got is not None:
+                return got
+        if w.shape[-1] == 1 and w.shape[-2] == 1 and stride == 1 and pad == 0 and out_dtype is None:
+            got = self.conv1x1_pw(w, b, ins, act, out, residual)
             if got is not None:
                 return got
         pc = self.pack(w, b)

@@ -125,6 +125,40 @@ def conv_halo(ins, pk, s2d, B, H, W, out, act="none", residual=None):
                                 out, stream_ptr()))
 
 
+PW_RING = 8
+
+
+class PackedPw:
+    """Register-stream packing of a 1x1 conv for ccnet_conv_pw (include/ccnet_hip.h): w (Cout, Cin[, 1, 1]), Cin % 64 == 0,
+    Cout % 64 == 0."""
+
+    def __init__(self, w, b, device):
+        w = w.to(torch.float64).reshape(w.shape[0], -1)
+        cout, cin = w.shape
+        assert cin % 64 == 0 and cout % 64 == 0
+        self.cout, self.cin = cout, cin
+        # [n64][j][row][ks][kq][e] -> [n64][ks][j][kq][row][e]: per 64 output channels, k-step major, n-tile; a fragment is
+        # [kq (lane >> 4)][row (lane & 15)][8]
+        f = w.reshape(cout // 64, 4, 16, cin // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).reshape(cout // 64, -1, 512)
+        f = torch.cat([f, f[:, :PW_RING]], 1)  # the ring prefetches across the tile boundary: the stream's head again
+        assert f.numel() == int(lib().ccnet_conv_pw_stream_elems(cin, cout))
+        self.weight = f.to(torch.bfloat16).to(device).contiguous()
+        self.bias = None if b is None else b.to(torch.float32).to(device).contiguous()
+
+
+def conv_pw_ok(dtype, out_dtype, ins, cout, out, residual=None):
+    """Shapes ccnet_conv_pw takes (the C entry point validates again)."""
+    return (dtype == BF16 and (out_dtype is None or out_dtype == BF16) and cout % 64 == 0 and len(ins) in (1, 2)
+            and all(s.shift <= 2 and s.C % 64 == 0 and s.ldc % 8 == 0 and s.coff % 8 == 0 for s in ins)
+            and out.ldc % 4 == 0 and out.coff % 4 == 0 and (residual is None or (residual.ldc % 4 == 0 and residual.coff % 4 == 0)))
+
+
+def conv_pw(ins, pk, B, H, W, out, act="none", residual=None):
+    arr = (Slice * len(ins))(*ins)
+    check(lib().ccnet_conv_pw(arr, len(ins), B, H, W, pk.cout, pk.weight.data_ptr(), None if pk.bias is None else pk.bias.data_ptr(),
+                              ACT[act], null_slice() if residual is None else residual, out, stream_ptr()))
+
+
 class PackedCsp:
     """Fragment-packed weights of one CSPLayer with a single bottleneck for ccnet_csp_fused (include/ccnet_hip.h):
     mats = [(w OIHW fp64, b fp64)] for [conv1;conv2], bottleneck conv1, bottleneck conv2 (3x3), conv3."""

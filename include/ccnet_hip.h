@@ -96,6 +96,20 @@ size_t ccnet_conv_halo_stream_elems(int Cin_virtual, int Cout);
 int ccnet_conv_halo(const ccnet_slice* in, int nseg, int s2d, int B, int H, int W, int Cout, const void* wstream_dev,
                     const float* bias_dev, int act, ccnet_slice residual, ccnet_slice out, ccnet_stream stream);
 
+/* ---- 1x1 Conv-BN-act with register-streamed weights (bf16) ---------------------------------------------------
+ * The same operator as ccnet_conv2d for BaseConv k1 s1 (network/model_block.py:37-58) over a channel concat of one or two
+ * inputs (torch.cat, network/net.py:208-210), each possibly nearest-upsampled (slice.shift, nn.Upsample network/net.py:103),
+ * on a kernel built like ccnet_conv_halo: pixels staged in LDS, weights streamed from L2 into registers (conv_pw.hip).
+ *   in: 1-2 bf16 slices, each a multiple of 64 channels, shift <= 2; H, W: logical (upsampled) size = output size;
+ *   Cout % 64 == 0; out / residual (ptr may be NULL; added after the activation) bf16 with channel offsets % 4 == 0.
+ *   wstream_dev: bf16, ccnet_conv_pw_stream_elems(Cin, Cout) elements: for each block of 64 output channels, for each 32-channel
+ *   k-step, for each 16-row n-tile: one MFMA A-operand fragment [64 lanes][8], then a copy of the block's first 8 fragments
+ *   (ccnet_amd/ops.py:PackedPw).  bias_dev: fp32[Cout] or NULL.
+ * Anything else: CCNET_EINVAL (callers use ccnet_conv2d).  Results are bit-identical to ccnet_conv2d's (same k order). */
+size_t ccnet_conv_pw_stream_elems(int Cin, int Cout);
+int ccnet_conv_pw(const ccnet_slice* in, int nseg, int B, int H, int W, int Cout, const void* wstream_dev, const float* bias_dev,
+                  int act, ccnet_slice residual, ccnet_slice out, ccnet_stream stream);
+
 /* ---- a whole CSPLayer with one bottleneck in one launch (bf16) ---------------------------------------------
  * Replaces CSPLayer.forward with n = 1 (network/model_block.py:86-116) and the Bottleneck inside it (:193-218):
  *   x_1 = conv1(x); x_2 = conv2(x); x_1 = [x_1 +] conv_b2(conv_b1(x_1)); out = conv3(cat(x_1, x_2))

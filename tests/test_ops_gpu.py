@@ -319,6 +319,64 @@ def test_conv_halo_is_run_to_run_identical_and_close_to_the_lds_weight_kernel():
     assert torch.equal(ob[:B].view(torch.int16), outs[0].view(torch.int16)) and torch.equal(ob[7 * B:].view(torch.int16), outs[0].view(torch.int16))
 
 
+PW_CASES = [
+    # B, H, W, [(cin, shift, ldc, coff)], cout, act, residual
+    (4, 20, 20, [(512, 0, 512, 0)], 512, "silu", False),
+    (3, 40, 40, [(256, 1, 256, 0), (256, 0, 256, 0)], 256, "silu", False),     # upsampled first segment (PAN concat)
+    (2, 12, 20, [(128, 0, 128, 0)], 64, "none", True),                          # 64-channel tiles, a partial tile of 224 rows
+    (1, 7, 9, [(64, 0, 64, 0), (64, 0, 64, 0)], 128, "relu", False),            # one partial tile (63 pixels), runtime activation
+    (2, 16, 16, [(192, 0, 320, 64)], 128, "silu", True),                        # a slice of a wider buffer, three chunks
+    (5, 8, 8, [(64, 2, 64, 0), (128, 1, 192, 64)], 192, "silu", False),         # both segments upsampled (x4, x2)
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES)
+def test_conv_pw_equals_conv2d_bitwise_and_matches_torch(case):
+    """ccnet_conv_pw (pixels in LDS, weights streamed into registers) against ccnet_conv2d on the same operands: bit for bit (same
+    MFMA shape and k order, fp32 accumulators from zero, bias added to the finished sum), and both against torch."""
+    ops = _ops()
+    B, H, W, segs, cout, act, use_res = case
+    g = torch.Generator().manual_seed(101 + cout + H)
+    cin = sum(c for c, _, _, _ in segs)
+    xs, ts, sls = [], [], []
+    for c, sh, ldc, coff in segs:
+        x = torch.randn(B, c, H >> sh, W >> sh, generator=g)
+        t = to_nhwc(x, 1, ldc=ldc, coff=coff)
+        xs.append(F.interpolate(q(x, 1), scale_factor=1 << sh, mode="nearest") if sh else q(x, 1))
+        ts.append(t)
+        sls.append(ops.sl(t, coff, c, shift=sh))
+    w = torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)
+    bias = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(B, cout, H, W, generator=g) if use_res else None
+    rt = to_nhwc(res, 1) if use_res else None
+    pk, pc = ops.PackedPw(w, bias, DEV), ops.PackedConv(w, bias, 1, DEV)
+    out = torch.zeros(B, H, W, cout + 8, dtype=torch.bfloat16, device=DEV)
+    ref = torch.zeros(B, H, W, cout + 8, dtype=torch.bfloat16, device=DEV)
+    ops.conv_pw(sls, pk, B, H, W, ops.sl(out, 4, cout), act, ops.sl(rt) if use_res else None)
+    ops.conv2d(sls, pc, B, H, W, 1, 0, ops.sl(ref, 4, cout), act, ops.sl(rt) if use_res else None)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    y = F.conv2d(torch.cat(xs, 1), q(w, 1), bias)
+    y = {"silu": F.silu, "relu": F.relu, "none": lambda v: v}[act](y)
+    if use_res:
+        y = y + q(res, 1)
+    assert rel(from_nhwc(out, 4, cout), y) < tol(1)
+    assert float(out[..., :4].float().abs().max()) == 0.0 and float(out[..., 4 + cout:].float().abs().max()) == 0.0   # neighbours untouched
+
+
+def test_conv_pw_rejects_what_it_does_not_take():
+    ops = _ops()
+    with pytest.raises(Exception):
+        ops.PackedPw(torch.zeros(64, 96, 1, 1), None, DEV)          # Cin % 64
+    pk = ops.PackedPw(torch.zeros(64, 64, 1, 1), None, DEV)
+    x = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device=DEV)
+    o = torch.zeros(1, 4, 4, 64, dtype=torch.float32, device=DEV)
+    with pytest.raises(Exception):
+        ops.conv_pw([ops.sl(x, 0, 32)], pk, 1, 4, 4, ops.sl(x.clone()), "silu")    # a 32-channel slice
+    with pytest.raises(Exception):
+        ops.conv_pw([ops.sl(x, shift=3)], pk, 1, 4, 4, ops.sl(x.clone()), "silu")  # upsampling by 8
+
+
 @pytest.mark.parametrize("code", [0, 1])
 def test_conv3x3_two_segments_patch_kernel(code):
     """3x3 over torch.cat([a, b], 1) at a 16-aligned width (MobileViT conv4, network/model_block.py:296-297): the halo-patch
