@@ -42,6 +42,8 @@ def lib():
         L.ccnet_conv2d.argtypes = [C.POINTER(ConvDesc), vp]
         L.ccnet_conv_halo_stream_elems.argtypes = [i32, i32]
         L.ccnet_conv_halo_stream_elems.restype = sz
+        L.ccnet_conv_halo_s2_stream_elems.argtypes = [i32, i32]
+        L.ccnet_conv_halo_s2_stream_elems.restype = sz
         L.ccnet_conv_halo.argtypes = [C.POINTER(Slice), i32, i32, i32, i32, i32, i32, vp, vp, i32, Slice, Slice, vp]
         L.ccnet_conv_pw_stream_elems.argtypes = [i32, i32]
         L.ccnet_conv_pw_stream_elems.restype = sz

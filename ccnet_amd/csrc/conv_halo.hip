@@ -21,6 +21,13 @@
 // banks once, for any starting row (fragments start at arbitrary rows: tap shifts).
 // SpaceToDepth: the conv is 3x3 over the virtual (H/2, W/2, 4C) tensor whose channel (2dy+dx)*C + c is stored pixel
 // (2y+dy, 2x+dx), channel c; a 32-channel chunk lies inside one (dy, dx), which only changes the patch fill's source address.
+// Stride 2 (MODE 2: BaseConv k3 s2 p1, the downsampling convs of net_deploy / net_small_target): out(y, x) reads stored rows
+// 2y-1, 2y, 2y+1 = virtual row y-1 phase dy=1, virtual row y phases dy=0 and dy=1 -- a 2x2 conv over the same virtual tensor in
+// which a chunk of phase (dy, dx) only has the taps its phase reaches: (0,0) one, (0,1) and (1,0) two, (1,1) four.  Nine
+// (tap, phase) pairs, exactly the nine taps of the 3x3.  To keep the chunk loop free of divergent code paths (a four-way branch
+// over differently unrolled tap sequences spilled 600 registers) every pass over a staged chunk is TWO taps with run-time
+// offsets: passes vq = 0..4 are phase (0,0) [its tap + a zero-weight one], (0,1), (1,0), (1,1) first half, (1,1) second half
+// (that phase's chunks are staged twice); 8 fragments per pass, an 8-deep ring, ten taps multiplied for nine needed.
 #include <stdlib.h>
 #include <mutex>
 #include "conv_common.h"
@@ -89,8 +96,35 @@ struct HaloQ {
 #define HALO_ABL 0   // timing ablations (wrong results): 1 = pixel fragments read once per chunk, 2 = no weight refills
 #endif
 
-template <int BN, bool LIN, bool S2D, int ACT>
+// One tap of a stride-2 pass: patch offset (KY, KX) in {0,1}^2 as wave-uniform run-time values, ring slots SB .. SB + 3
+#define HALO_TAP2(KY, KX, SB)                                                                                                      \
+    {                                                                                                                              \
+        u32x4 fa[MT];                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+        if constexpr (LIN) {                                                                                                       \
+            const int r0 = lin_base + (KY) * lin_wp + (KX);                                                                        \
+            const int a0 = r0 * HROWB + ((fq ^ ((r0 >> 1) & 3)) << 4);                                                             \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) fa[i] = *(const u32x4*)(pt + a0 + i * MSTR);                            \
+        } else {                                                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                       \
+                const int r0 = (wm * MT + i + (KY)) * 18 + (KX) + fr;                                                              \
+                fa[i] = *(const u32x4*)(pt + r0 * HROWB + ((fq ^ ((r0 >> 1) & 3)) << 4));                                          \
+            }                                                                                                                      \
+        }                                                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                                           \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                         \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[(SB) + j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0); \
+            ring[(SB) + j] = *(const u32x4*)(wp + RING * 1024 + loff);                                                             \
+            wp += 1024;                                                                                                            \
+        }                                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                         \
+    }
+
+// MODE: 0 = 3x3 s1 p1, 1 = SpaceToDepth + 3x3, 2 = 3x3 s2 p1
+template <int BN, bool LIN, int MODE, int ACT>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloQ p) {
+    constexpr bool S2D = MODE != 0, ST2 = MODE == 2;   // both read the un-shuffled tensor through the virtual (H/2, W/2, 4C) one
+    constexpr int RING = ST2 ? 8 : HRING;
     constexpr int MT = BN == 128 ? 8 : 4, NT = 4;
     constexpr int PXW = MT * 16;                             // pixels per wave
     constexpr int MSTR = LIN ? 16 * HROWB : 18 * HROWB;      // LDS bytes between a wave's m-tiles
@@ -154,7 +188,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloQ p) {
     auto chunk_src = [&](int cc, bool& s1, unsigned& soff) {
         if (S2D) {
             const int v0 = cc * HCH;
-            const int q = v0 / p.Creal, c0 = v0 - q * p.Creal;   // q = 2 dy + dx
+            int q = v0 / p.Creal;                                  // q = 2 dy + dx (stride 2: pass 0..4, passes 3 and 4 are phase 3)
+            const int c0 = v0 - q * p.Creal;
+            if (ST2 && q == 4) q = 3;
             s1 = false;
             soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((q >> 1) * p.Win + (q & 1)) * ldcB0 + (unsigned)c0 * 2u));
         } else {
@@ -200,10 +236,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloQ p) {
     const unsigned char* wbase = p.wstream + (size_t)n64 * p.wstride;   // wave uniform
     const unsigned char* wp = wbase;
     const int loff = lane * 16;
-    u32x4 ring[HRING];
+    u32x4 ring[RING];
 #pragma unroll
-    for (int k = 0; k < HRING; ++k) ring[k] = *(const u32x4*)(wp + k * 1024 + loff);
-    const long long wrewind = (long long)p.nchunks * HFRAGS * 1024;
+    for (int k = 0; k < RING; ++k) ring[k] = *(const u32x4*)(wp + k * 1024 + loff);
+    const long long wrewind = (long long)p.nchunks * (ST2 ? 8 : HFRAGS) * 1024;   // stride 2: 8 per pass, nchunks = passes
+    const int cpp = ST2 ? p.Creal / HCH : 1;   // chunks per phase
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -312,7 +349,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloQ p) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) patch_piece(i, (int)((ci + 1) & 1), pf_s1, pf_soff);
         }
-        HALO_TAP(0) HALO_TAP(1) HALO_TAP(2) HALO_TAP(3) HALO_TAP(4) HALO_TAP(5) HALO_TAP(6) HALO_TAP(7) HALO_TAP(8)
+        if constexpr (ST2) {
+            // pass vq over a staged chunk: two taps (offsets into the 2 x 2 window).  vq 0: (1,1) + the zero-weight tap; 1: (1,0)
+            // (1,1); 2: (0,1) (1,1); 3: (0,0) (0,1); 4: (1,0) (1,1)
+            const int vq = __builtin_amdgcn_readfirstlane(cur_cc / cpp);
+            const int kya = (vq == 2 || vq == 3) ? 0 : 1, kxa = (vq == 0 || vq == 2) ? 1 : 0;
+            const int kyb = vq == 3 ? 0 : 1, kxb = 1;
+            HALO_TAP2(kya, kxa, 0) HALO_TAP2(kyb, kxb, 4)
+        } else {
+            HALO_TAP(0) HALO_TAP(1) HALO_TAP(2) HALO_TAP(3) HALO_TAP(4) HALO_TAP(5) HALO_TAP(6) HALO_TAP(7) HALO_TAP(8)
+        }
         if (next_chunk) pf_advance();
         if (++cur_cc == p.nchunks) {
             cur_cc = 0;
@@ -324,17 +370,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloQ p) {
         // The next chunk's patch pieces were issued before this chunk's 36 ring loads, and vector-memory operations return in
         // order: with at most HRING of them outstanding the pieces have landed.  (This chunk's last MFMAs already waited for
         // ring loads issued after the pieces, so the wait is normally satisfied on arrival.)
-        static_assert(HRING == 9, "the immediate below encodes vmcnt(HRING)");
-        __builtin_amdgcn_s_waitcnt(0x0079);   // vmcnt(9) lgkmcnt(0)
+        static_assert(HRING == 9, "the immediates below encode vmcnt(RING)");
+        if constexpr (ST2) __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0): every chunk issues at least 8 ring loads
+        else __builtin_amdgcn_s_waitcnt(0x0079);                 // vmcnt(9) lgkmcnt(0)
         if (!(HALO_ABL & 4)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
     if (pending) epilogue(pend_tile);
 }
 
-template <int BN, bool LIN, bool S2D, int ACT>
+template <int BN, bool LIN, int MODE, int ACT>
 int launch_halo_k(const HaloQ& p, hipStream_t st) {
-    auto kernel = conv_halo_kernel<BN, LIN, S2D, ACT>;
+    auto kernel = conv_halo_kernel<BN, LIN, MODE, ACT>;
     constexpr int LDS = 2 * HPATCH + 6 * 256 * 4;   // two patch buffers + the per-tile pixel table
     static std::mutex mu;
     static int cached[16] = {0};
@@ -361,17 +408,18 @@ int launch_halo_k(const HaloQ& p, hipStream_t st) {
     return CCNET_OK;
 }
 
-template <int BN, bool LIN, bool S2D>
+template <int BN, bool LIN, int MODE>
 int launch_halo_act(const HaloQ& p, hipStream_t st) {
-    if (p.act == CCNET_ACT_SILU) return launch_halo_k<BN, LIN, S2D, CCNET_ACT_SILU>(p, st);
-    if (!S2D && p.act == CCNET_ACT_NONE) return launch_halo_k<BN, LIN, S2D, CCNET_ACT_NONE>(p, st);
-    return launch_halo_k<BN, LIN, S2D, ACT_RUNTIME>(p, st);
+    if (p.act == CCNET_ACT_SILU) return launch_halo_k<BN, LIN, MODE, CCNET_ACT_SILU>(p, st);
+    if (MODE == 0 && p.act == CCNET_ACT_NONE) return launch_halo_k<BN, LIN, MODE, CCNET_ACT_NONE>(p, st);
+    return launch_halo_k<BN, LIN, MODE, ACT_RUNTIME>(p, st);
 }
 
 template <int BN>
-int launch_halo(const HaloQ& p, bool lin, bool s2d, hipStream_t st) {
-    if (lin) return s2d ? launch_halo_act<BN, true, true>(p, st) : launch_halo_act<BN, true, false>(p, st);
-    return s2d ? launch_halo_act<BN, false, true>(p, st) : launch_halo_act<BN, false, false>(p, st);
+int launch_halo(const HaloQ& p, bool lin, int mode, hipStream_t st) {
+    if (mode == 2) return lin ? launch_halo_act<BN, true, 2>(p, st) : launch_halo_act<BN, false, 2>(p, st);
+    if (lin) return mode ? launch_halo_act<BN, true, 1>(p, st) : launch_halo_act<BN, true, 0>(p, st);
+    return mode ? launch_halo_act<BN, false, 1>(p, st) : launch_halo_act<BN, false, 0>(p, st);
 }
 
 void halo_magic(unsigned d, unsigned* magic, unsigned* shift) {
@@ -388,12 +436,19 @@ extern "C" size_t ccnet_conv_halo_stream_elems(int Cin, int Cout) {
     return (size_t)(Cout / 64) * ((size_t)(Cin / HCH) * HFRAGS + HRING) * 512;
 }
 
+// stride-2 stream: five passes of two taps over the chunks of C, 8 fragments per pass and chunk
+extern "C" size_t ccnet_conv_halo_s2_stream_elems(int C, int Cout) {
+    if (C <= 0 || Cout <= 0 || (C % HCH) != 0 || (Cout % 64) != 0) return 0;
+    return (size_t)(Cout / 64) * ((size_t)(C / HCH) * 40 + 8) * 512;
+}
+
 extern "C" int ccnet_conv_halo(const ccnet_slice* in, int nseg, int s2d, int B, int H, int W, int Cout, const void* wstream_dev,
                                const float* bias_dev, int act, ccnet_slice residual, ccnet_slice out, ccnet_stream stream) {
     CC_REQUIRE(in && (nseg == 1 || nseg == 2) && wstream_dev, "conv_halo: null pointer / bad segment count");
     CC_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && (Cout % 64) == 0, "conv_halo: bad sizes (B=%d H=%d W=%d Cout=%d; Cout must be a multiple of 64)", B, H, W, Cout);
     CC_REQUIRE(act >= CCNET_ACT_NONE && act <= CCNET_ACT_LRELU, "conv_halo: unknown activation %d", act);
-    CC_REQUIRE(!s2d || (nseg == 1 && (H % 2) == 0 && (W % 2) == 0), "conv_halo: SpaceToDepth mode takes one input of even size");
+    CC_REQUIRE(s2d >= 0 && s2d <= 2, "conv_halo: mode must be 0 (3x3), 1 (SpaceToDepth + 3x3) or 2 (3x3 stride 2)");
+    CC_REQUIRE(!s2d || (nseg == 1 && (H % 2) == 0 && (W % 2) == 0), "conv_halo: SpaceToDepth / stride-2 modes take one input of even size");
     CC_REQUIRE(((uintptr_t)wstream_dev % 16) == 0 && ((uintptr_t)bias_dev % 16) == 0, "conv_halo: weights / bias must be 16-byte aligned");
     HaloQ p{};
     int ctot = 0;
@@ -415,7 +470,7 @@ extern "C" int ccnet_conv_halo(const ccnet_slice* in, int nseg, int s2d, int B, 
     p.Hin = H; p.Win = W;
     p.Hv = s2d ? H / 2 : H; p.Wv = s2d ? W / 2 : W;
     p.B = B; p.Cout = Cout;
-    p.nchunks = cvirt / HCH;
+    p.nchunks = s2d == 2 ? 5 * ctot / HCH : cvirt / HCH;   // stride 2: five passes over the four phases' chunks
     const long long M = (long long)B * p.Hv * p.Wv;
     CC_REQUIRE(M < (1ll << 30), "conv_halo: too many pixels");
     // geometry: 16 x 16 tiles, or the linear padded space where that wastes less (narrow maps)
@@ -436,7 +491,7 @@ extern "C" int ccnet_conv_halo(const ccnet_slice* in, int nseg, int s2d, int B, 
         p.Wp = 18;
     }
     p.wstream = (const unsigned char*)wstream_dev;
-    p.wstride = ((unsigned long long)p.nchunks * HFRAGS + HRING) * 1024ull;
+    p.wstride = s2d == 2 ? ((unsigned long long)p.nchunks * 8 + 8) * 1024ull : ((unsigned long long)p.nchunks * HFRAGS + HRING) * 1024ull;
     p.bias = bias_dev;
     p.act = act;
     CC_REQUIRE(out.ptr && out.shift == 0 && out.C == Cout && out.coff >= 0 && out.ldc >= out.coff + out.C && (out.ldc % 4) == 0 && (out.coff % 4) == 0 &&
@@ -448,9 +503,10 @@ extern "C" int ccnet_conv_halo(const ccnet_slice* in, int nseg, int s2d, int B, 
         p.res_ptr = (const unsigned char*)residual.ptr; p.res_ldc = residual.ldc; p.res_coff = residual.coff;
     }
     p.xcd = cc_xcd_remap();
-    const double flops = 2.0 * (double)M * Cout * 9.0 * cvirt;
-    const double bytes = ((double)B * H * W * ctot + (double)Cout * 9.0 * cvirt) * 2.0 + (double)M * Cout * (2.0 + (residual.ptr ? 2.0 : 0.0));
-    const bool s2 = s2d != 0;
+    const double kreal = s2d == 2 ? 9.0 * ctot : 9.0 * cvirt;   // stride 2: the nine taps of the 3x3 over the stored channels
+    const double flops = 2.0 * (double)M * Cout * kreal;
+    const double bytes = ((double)B * H * W * ctot + (double)Cout * kreal) * 2.0 + (double)M * Cout * (2.0 + (residual.ptr ? 2.0 : 0.0));
+    const int s2 = s2d;
     // 128 output channels per workgroup wherever Cout allows.  A rule that switched to 64-channel tiles when the 128-channel ones
     // leave workgroup slots empty looked better layer by layer in a microbenchmark and cost 5 % of the MFMA-bound group inside
     // the network (same-box A/B, scripts/ab_env.sh: 2.35 against 2.23 ms per forward).  Both shapes accumulate a pixel's sum in the

@@ -245,8 +245,14 @@ class Compiler:
 
     # ---- emitters
     def conv3x3_halo(self, w, b, ins, s2d, act, out=None, residual=None):
-        """3x3 s1 p1 (or SpaceToDepth + 3x3 with the un-shuffled input) on ccnet_conv_halo when the shape qualifies, else None."""
+        """3x3 s1 p1 (s2d False), SpaceToDepth + 3x3 with the un-shuffled input (True) or 3x3 s2 p1 (2) on ccnet_conv_halo when the
+        shape qualifies, else None."""
         if self.dtype != BF16 or os.environ.get("CCNET_NO_HALO_CONV", "0") != "0":
+            return None
+        # stride 2 on this kernel (five two-tap passes, ten taps multiplied for nine) measured EQUAL to the implicit GEMM inside the
+        # networks that have such layers (same-box A/B: net_deploy at 32 images 2.164 / 2.176 against 2.172 / 2.169 ms per step;
+        # single layers +16 % ... -10 %), so the implicit GEMM keeps them; CCNET_HALO_S2=1 switches them over
+        if s2d == 2 and os.environ.get("CCNET_HALO_S2", "0") == "0":
             return None
         x0 = ins[0]
         cout, cvirt = w.shape[0], w.shape[1]
@@ -264,12 +270,12 @@ class Compiler:
         # CCNET_HALO_SMALL_MAPS=0 brings the old rule back.
         if Ho * Wo <= 400 and cout < 512 and os.environ.get("CCNET_HALO_SMALL_MAPS", "1") == "0":
             return None
-        pk = ops.PackedHalo(w, b, self.dev)
+        pk = ops.PackedHaloS2(w, b, self.dev) if s2d == 2 else ops.PackedHalo(w, b, self.dev)
         self.keep.append(pk)
         if out is None:
             out = self.new(cout, Ho, Wo)
         assert (out.H, out.W, out.C) == (Ho, Wo, cout), "conv output slice mismatch"
-        ops.conv_halo([t.sl() for t in ins], pk, s2d, self.B, x0.H, x0.W, out.sl(), act, None if residual is None else residual.sl())
+        ops.conv_halo([t.sl() for t in ins], pk, int(s2d), self.B, x0.H, x0.W, out.sl(), act, None if residual is None else residual.sl())
         return out
 
     def conv1x1_pw(self, w, b, ins, act, out=None, residual=None):
@@ -296,6 +302,10 @@ class Compiler:
     def conv_w(self, w, b, ins, stride, pad, act, out=None, residual=None, out_dtype=None):
         if w.shape[-1] == 3 and w.shape[-2] == 3 and stride == 1 and pad == 1 and out_dtype is None:
             got = self.conv3x3_halo(w, b, ins, False, act, out, residual)
+            if got is not None:
+                return got
+        if w.shape[-1] == 3 and w.shape[-2] == 3 and stride == 2 and pad == 1 and out_dtype is None:
+            got = self.conv3x3_halo(w, b, ins, 2, act, out, residual)
             if got is not None:
                 return got
         if w.shape[-1] == 1 and w.shape[-2] == 1 and stride == 1 and pad == 0 and out_dtype is None:

@@ -111,6 +111,36 @@ class PackedHalo:
         self.bias = None if b is None else b.to(torch.float32).to(device).contiguous()
 
 
+# pass vq over the staged chunks -> the two 3x3 taps (ky, kx) it multiplies (None: four zero fragments); passes 0..2 read the
+# chunks of phase (dy, dx) = (0,0), (0,1), (1,0), passes 3 and 4 both those of phase (1,1)
+HALO_S2_PASSES = [((1, 1), None), ((1, 0), (1, 2)), ((0, 1), (2, 1)), ((0, 0), (0, 2)), ((2, 0), (2, 2))]
+
+
+class PackedHaloS2:
+    """Register-stream packing of a 3x3 STRIDE-2 pad-1 conv for ccnet_conv_halo mode 2 (include/ccnet_hip.h): w (Cout, C, 3, 3),
+    C % 32 == 0, Cout % 64 == 0.  Per 64 output channels: for each pass (HALO_S2_PASSES), for each 32-channel chunk of C, two taps of
+    four n-tile fragments each."""
+
+    def __init__(self, w, b, device):
+        w = w.to(torch.float64)
+        cout, cin, kh, kw = w.shape
+        assert (kh, kw) == (3, 3) and cin % 32 == 0 and cout % 64 == 0
+        self.cout, self.cin = cout, cin
+        w8 = w.reshape(cout // 64, 4, 16, cin // 32, 4, 8, 3, 3)   # [n64][j][row][cc][kq][e][ky][kx]
+        zero = torch.zeros(cout // 64, 4, 512, dtype=torch.float64)
+        seq = []
+        for taps in HALO_S2_PASSES:
+            for cc in range(cin // 32):
+                for tap in taps:
+                    # [n64][j][row][kq][e] -> [n64][j][kq][row][e]: a fragment is [kq (lane >> 4)][row (lane & 15)][8]
+                    seq.append(zero if tap is None else w8[:, :, :, cc, :, :, tap[0], tap[1]].permute(0, 1, 3, 2, 4).reshape(cout // 64, 4, 512))
+        f = torch.cat(seq, 1)
+        f = torch.cat([f, f[:, :8]], 1)  # the ring prefetches across the tile boundary: the stream's head again
+        assert f.numel() == int(lib().ccnet_conv_halo_s2_stream_elems(cin, cout))
+        self.weight = f.to(torch.bfloat16).to(device).contiguous()
+        self.bias = None if b is None else b.to(torch.float32).to(device).contiguous()
+
+
 def conv_halo_ok(dtype, out_dtype, ins, cin_virtual, cout, out, residual=None):
     """Shapes ccnet_conv_halo takes (the C entry point validates again)."""
     return (dtype == BF16 and (out_dtype is None or out_dtype == BF16) and cout % 64 == 0 and cin_virtual % 32 == 0
@@ -119,8 +149,9 @@ def conv_halo_ok(dtype, out_dtype, ins, cin_virtual, cout, out, residual=None):
 
 
 def conv_halo(ins, pk, s2d, B, H, W, out, act="none", residual=None):
+    """s2d: False / 0 = 3x3 s1 p1, True / 1 = SpaceToDepth + 3x3 (PackedHalo over the 4C virtual channels), 2 = 3x3 s2 p1 (PackedHaloS2)."""
     arr = (Slice * len(ins))(*ins)
-    check(lib().ccnet_conv_halo(arr, len(ins), 1 if s2d else 0, B, H, W, pk.cout, pk.weight.data_ptr(),
+    check(lib().ccnet_conv_halo(arr, len(ins), int(s2d), B, H, W, pk.cout, pk.weight.data_ptr(),
                                 None if pk.bias is None else pk.bias.data_ptr(), ACT[act], null_slice() if residual is None else residual,
                                 out, stream_ptr()))
 

@@ -91,8 +91,15 @@ int ccnet_conv2d(const ccnet_conv_desc* d, ccnet_stream stream);
  *   wstream_dev: bf16, ccnet_conv_halo_stream_elems(Cin_virtual, Cout) elements: for each block of 64 output channels, for each
  *   32-channel chunk, for each tap (ky*3+kx), for each 16-row n-tile: one MFMA A-operand fragment [64 lanes][8] (lane l: row
  *   l & 15, k (l >> 4)*8..+7), then a copy of the block's first 9 fragments (ccnet_amd/ops.py:PackedHalo).  bias_dev: fp32[Cout] or NULL.
+ * s2d = 2: BaseConv k3 s2 p1 (the downsampling convs of net_deploy / net_small_target, network/net_deploy.py:44-60) on the same
+ *   kernel: `in` is the (B, H, W, C) tensor (one slice, H and W even), the output is (H/2, W/2); wstream_dev has
+ *   ccnet_conv_halo_s2_stream_elems(C, Cout) elements: per block of 64 output channels, five passes over the 32-channel chunks
+ *   of C, each pass two taps (ky, kx) of four n-tile fragments per chunk -- pass 0: (1,1) and four zero fragments; 1: (1,0),
+ *   (1,2); 2: (0,1), (2,1); 3: (0,0), (0,2); 4: (2,0), (2,2) -- then a copy of the block's first 8 fragments
+ *   (ccnet_amd/ops.py:PackedHaloS2).
  * Anything else: CCNET_EINVAL (callers use ccnet_conv2d).  Rounding points are ccnet_conv2d's; the accumulation order differs. */
 size_t ccnet_conv_halo_stream_elems(int Cin_virtual, int Cout);
+size_t ccnet_conv_halo_s2_stream_elems(int C, int Cout);
 int ccnet_conv_halo(const ccnet_slice* in, int nseg, int s2d, int B, int H, int W, int Cout, const void* wstream_dev,
                     const float* bias_dev, int act, ccnet_slice residual, ccnet_slice out, ccnet_stream stream);
 

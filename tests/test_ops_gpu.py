@@ -319,6 +319,46 @@ def test_conv_halo_is_run_to_run_identical_and_close_to_the_lds_weight_kernel():
     assert torch.equal(ob[:B].view(torch.int16), outs[0].view(torch.int16)) and torch.equal(ob[7 * B:].view(torch.int16), outs[0].view(torch.int16))
 
 
+HALO_S2_CASES = [
+    # B, H, W, C, cout, act, residual
+    (2, 32, 32, 64, 128, "silu", False),      # 16 x 16 outputs: one 2D tile per image
+    (3, 40, 40, 32, 64, "silu", False),       # 20-wide outputs: linear geometry, 64-channel tiles, one chunk per phase
+    (1, 18, 22, 96, 64, "relu", False),       # 9 x 11 outputs: partial tiles, three chunks per phase, runtime activation
+    (2, 160, 96, 64, 128, "silu", True),      # 80 x 48 outputs: 2D tiles with a partial column of tiles, residual
+    (2, 24, 40, 128, 256, "none", False),     # two column blocks of workgroups
+]
+
+
+@pytest.mark.parametrize("case", HALO_S2_CASES)
+def test_conv_halo_stride2_matches_torch_and_the_implicit_gemm(case):
+    """ccnet_conv_halo mode 2 (BaseConv k3 s2 p1 as five two-tap passes over the phases of the 2x2 pixel groups) against torch and
+    against ccnet_conv2d on the same operands (same rounding points, another accumulation order), twice (bit-identical)."""
+    ops = _ops()
+    B, H, W, C, cout, act, use_res = case
+    g = torch.Generator().manual_seed(77 + C + H)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(cout, C, 3, 3, generator=g) / math.sqrt(C * 9)
+    bias = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(B, cout, H // 2, W // 2, generator=g) if use_res else None
+    xt, rt = to_nhwc(x, 1), (to_nhwc(res, 1) if use_res else None)
+    pk, pc = ops.PackedHaloS2(w, bias, DEV), ops.PackedConv(w, bias, 1, DEV)
+    outs = []
+    for _ in range(2):
+        o = torch.zeros(B, H // 2, W // 2, cout, dtype=torch.bfloat16, device=DEV)
+        ops.conv_halo([ops.sl(xt)], pk, 2, B, H, W, ops.sl(o), act, ops.sl(rt) if use_res else None)
+        outs.append(o)
+    ref = torch.zeros(B, H // 2, W // 2, cout, dtype=torch.bfloat16, device=DEV)
+    ops.conv2d([ops.sl(xt)], pc, B, H, W, 2, 1, ops.sl(ref), act, ops.sl(rt) if use_res else None)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    y = F.conv2d(q(x, 1), q(w, 1), bias, 2, 1)
+    y = {"silu": F.silu, "relu": F.relu, "none": lambda v: v}[act](y)
+    if use_res:
+        y = y + q(res, 1)
+    assert rel(from_nhwc(outs[0], 0, cout), y) < tol(1)
+    assert float((outs[0].float() - ref.float()).abs().max() / ref.float().abs().max()) < 1.6e-2
+
+
 PW_CASES = [
     # B, H, W, [(cin, shift, ldc, coff)], cout, act, residual
     (4, 20, 20, [(512, 0, 512, 0)], 512, "silu", False),
