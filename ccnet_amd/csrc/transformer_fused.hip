@@ -103,6 +103,34 @@ __device__ __forceinline__ void mm(f32x4 (&acc)[4][NTW], const unsigned char* sr
     }
 }
 
+// The same with a 16-deep ring: slots 0..7 in `ring`, 8..15 in `hi` (the FFN's look-ahead; see ffn()).  Every call consumes a
+// multiple of 16 fragments.
+#ifndef TF_FFN_RING16
+#define TF_FFN_RING16 1
+#endif
+template <int NTW, int KT, int ROWB>
+__device__ __forceinline__ void mm16(f32x4 (&acc)[4][NTW], const unsigned char* src, u32x4 (&ring)[RING], u32x4 (&hi)[8], const unsigned char*& wp,
+                                     int loff, const int (&lk)[4]) {
+    static_assert(RING == 8 && (NTW * KT) % 16 == 0, "a GEMM call must consume whole turns of the 16-deep ring");
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        u32x4 xb[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xb[mt] = *(const u32x4*)(src + lk[kt & 3] + mt * 16 * ROWB + (kt >> 2) * 256);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int slot = (kt * NTW + j) % 16;
+            u32x4& w = slot < 8 ? ring[slot & 7] : hi[slot & 7];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, xb[mt]), acc[mt][j], 0, 0, 0);
+            w = *(const u32x4*)(wp + 16 * 1024 + loff);
+            wp += 1024;
+        }
+        if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // An opaque copy of a lane-derived value.  The swizzled LDS addresses of the epilogues are invariant across the layer loops;
 // left alone, the compiler hoists dozens of them out of those loops and then spills them (hundreds of bytes of scratch per
 // lane).  Recomputing them per call from a laundered lane index costs a few VALU instructions beside thousands of MFMAs.
@@ -451,6 +479,15 @@ __global__ __launch_bounds__(NW * 64 * (TF_PAIR ? 2 : 1), TF_PAIR ? 1 : 2) void 
         pp += FF + E;
         f32x4 acc2[4][4];
         zero<4>(acc2);
+        // Inside the FFN (two thirds of the kernel's MFMAs, and the part with registers to spare since it runs in 128-wide chunks) the
+        // weight ring is 16 deep: eight more fragments are requested here, every refill looks 16 ahead, and at the end the upper
+        // half is simply dropped -- the stream position is a multiple of 16 fragments later, the lower half holds what an 8-deep
+        // ring would hold, and the next phase requests the upper half's fragments again (8 KB per wave and FFN).
+        u32x4 hi[8];
+        if (TF_FFN_RING16) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hi[i] = *(const u32x4*)(wp + (8 + i) * 1024 + loff);
+        }
 #pragma unroll 2
         for (int c = 0; c < FF / 128; ++c) {
             unsigned char* HT = (c & 1) ? RB : RA;
@@ -459,7 +496,8 @@ __global__ __launch_bounds__(NW * 64 * (TF_PAIR ? 2 : 1), TF_PAIR ? 1 : 2) void 
             for (int j = 0; j < 2; ++j) hb[j] = *(const float4*)(b1 + c * 128 + wave * 32 + j * 16 + fq * 4);
             f32x4 acc1[4][2];
             zero<2>(acc1);
-            mm<2, 8, 512>(acc1, X, ring, wp, loff, lx);
+            if (TF_FFN_RING16) mm16<2, 8, 512>(acc1, X, ring, hi, wp, loff, lx);
+            else mm<2, 8, 512>(acc1, X, ring, wp, loff, lx);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n0 = wave * 32 + j * 16 + fq * 4;  // column inside the chunk
@@ -472,7 +510,8 @@ __global__ __launch_bounds__(NW * 64 * (TF_PAIR ? 2 : 1), TF_PAIR ? 1 : 2) void 
                 }
             }
             TSYNC();
-            mm<4, 4, 256>(acc2, HT, ring, wp, loff, lq);
+            if (TF_FFN_RING16) mm16<4, 4, 256>(acc2, HT, ring, hi, wp, loff, lq);
+            else mm<4, 4, 256>(acc2, HT, ring, wp, loff, lq);
         }
         TSYNC();  // region A / B (and the LayerNorm table in C) are free again
         float4 b2v[4];
