@@ -52,6 +52,20 @@ static inline int cc_xcd_remap() {
     return v;
 }
 
+// Tile slots (blocks per output-channel slice) of a persistent grid of at most `resident` blocks split into ny slices: as many
+// as fit, no more than there are tiles, and a multiple of 8 where possible so that cc_tile_walk_sliced can keep tile
+// neighbours and the slices of a tile on one XCD (surplus blocks find their range empty and leave).
+static inline int cc_grid_x(int resident, int ny, unsigned ntiles) {
+    int gx = resident / ny;
+    if (gx < 1) gx = 1;
+    if ((unsigned)gx > ntiles) gx = (int)ntiles;
+    if (gx >= 8) {
+        const int up = (gx + 7) & ~7;
+        gx = up * ny <= resident ? up : (gx & ~7);
+    }
+    return gx;
+}
+
 // ---- device helpers -------------------------------------------------------------------------------------
 #ifdef __HIPCC__
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -73,6 +87,28 @@ __device__ __forceinline__ void cc_tile_walk(unsigned ntiles, int xcd, unsigned&
     } else {
         first = b;
         stride = g;
+        end = ntiles;
+    }
+}
+
+// The same walk for kernels whose workgroups also split the output channels into ny slices, on a ONE-dimensional grid of
+// gx * ny blocks (gx from cc_grid_x: a multiple of 8).  The slices of one tile slot are the blocks L, L + 8, .., L + 8 (ny - 1):
+// same XCD, dispatched next to each other, so the input rows they all read cross the fabric once and are L2 hits for the others.
+// (With the slices on blockIdx.y they were gx blocks apart in dispatch order, and on different L2s whenever gx % 8 != 0: the
+// 512-channel layers read their input 4-6 times from memory, rocprofv3 FETCH_SIZE.)
+__device__ __forceinline__ void cc_tile_walk_sliced(unsigned ntiles, int xcd, unsigned ny, unsigned& first, unsigned& stride, unsigned& end,
+                                                    unsigned& slice) {
+    const unsigned L = blockIdx.x, gx = gridDim.x / ny;
+    if (xcd && (gx & 7u) == 0u) {
+        const unsigned per = (ntiles + 7u) >> 3, x = L & 7u, idx = L >> 3;
+        slice = idx % ny;
+        stride = gx >> 3;
+        first = x * per + idx / ny;
+        end = min((x + 1u) * per, ntiles);
+    } else {
+        slice = L % ny;
+        first = L / ny;
+        stride = gx;
         end = ntiles;
     }
 }

@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloQ p) {
     constexpr int MSTR = LIN ? 16 * HROWB : 18 * HROWB;      // LDS bytes between a wave's m-tiles
     extern __shared__ __align__(16) unsigned char smem[];    // patch[2]
 
-    unsigned tile0, tstride, tend;
-    cc_tile_walk(p.ntiles, p.xcd, tile0, tstride, tend);
+    unsigned tile0, tstride, tend, nslice;
+    cc_tile_walk_sliced(p.ntiles, p.xcd, (unsigned)(p.Cout / BN), tile0, tstride, tend, nslice);
     if (tile0 >= tend) return;
     const unsigned my_tiles = (tend - tile0 + tstride - 1) / tstride;
     const unsigned total_chunks = my_tiles * (unsigned)p.nchunks;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloQ p) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = BN == 128 ? (wave >> 1) : wave, wn = BN == 128 ? (wave & 1) : 0;
     const int fr = lane & 15, fq = lane >> 4;
-    const int n64 = blockIdx.y * (BN / 64) + wn;
+    const int n64 = (int)nslice * (BN / 64) + wn;
 
     const __amdgpu_buffer_rsrc_t rsrcA0 = make_rsrc(p.seg[0].ptr, p.seg[0].span);
     const __amdgpu_buffer_rsrc_t rsrcA1 = make_rsrc(p.seg[1].ptr, p.seg[1].span);
@@ -400,10 +400,8 @@ int launch_halo_k(const HaloQ& p, hipStream_t st) {
         resident = cached[dev];
     }
     const int gy = p.Cout / BN;
-    int gx = resident / gy;
-    if (gx < 1) gx = 1;
-    if ((unsigned)gx > p.ntiles) gx = (int)p.ntiles;
-    hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(256), LDS, st, p);
+    const int gx = cc_grid_x(resident, gy, p.ntiles);
+    hipLaunchKernelGGL(kernel, dim3(gx * gy), dim3(256), LDS, st, p);
     CC_LAUNCH_CHECK();
     return CCNET_OK;
 }

@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwQ p) {
     constexpr int PXW = MT * 16;   // pixels per wave
     extern __shared__ __align__(16) unsigned char smem[];
 
-    unsigned tile0, tstride, tend;
-    cc_tile_walk(p.ntiles, p.xcd, tile0, tstride, tend);
+    unsigned tile0, tstride, tend, nslice;
+    cc_tile_walk_sliced(p.ntiles, p.xcd, (unsigned)(p.Cout / BN), tile0, tstride, tend, nslice);
     if (tile0 >= tend) return;
     const unsigned my_tiles = (tend - tile0 + tstride - 1) / tstride;
     const unsigned total_chunks = my_tiles * (unsigned)p.nchunks;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwQ p) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = BN == 128 ? (wave >> 1) : wave, wn = BN == 128 ? (wave & 1) : 0;
     const int fr = lane & 15, fq = lane >> 4;
-    const int n64 = blockIdx.y * (BN / 64) + wn;
+    const int n64 = (int)nslice * (BN / 64) + wn;
 
     const __amdgpu_buffer_rsrc_t rsrcA0 = make_rsrc(p.seg[0].ptr, p.seg[0].span);
     const __amdgpu_buffer_rsrc_t rsrcA1 = make_rsrc(p.seg[1].ptr, p.seg[1].span);
@@ -263,10 +263,8 @@ int launch_pw_k(const PwQ& p, hipStream_t st) {
         resident = cached[dev];
     }
     const int gy = p.Cout / BN;
-    int gx = resident / gy;
-    if (gx < 1) gx = 1;
-    if ((unsigned)gx > p.ntiles) gx = (int)p.ntiles;
-    hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(256), PW_LDS, st, p);
+    const int gx = cc_grid_x(resident, gy, p.ntiles);
+    hipLaunchKernelGGL(kernel, dim3(gx * gy), dim3(256), PW_LDS, st, p);
     CC_LAUNCH_CHECK();
     return CCNET_OK;
 }
