@@ -45,8 +45,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvQ
     static_assert(A_LOADS + B_LOADS + 2 * MT * NT < 64, "vmcnt is a 6-bit counter");
     __shared__ __align__(16) unsigned char smem[NST * BUF_BYTES];
 
-    unsigned tile0, tstride, tend;
-    cc_tile_walk(p.ntiles, p.xcd, tile0, tstride, tend);
+    unsigned tile0, tstride, tend, nslice;
+    cc_tile_walk_sliced(p.ntiles, p.xcd, (unsigned)((p.Cout + BN - 1) / BN), tile0, tstride, tend, nslice);
     if (tile0 >= tend) return;
     const unsigned my_tiles = (tend - tile0 + tstride - 1) / tstride;
     const unsigned total = my_tiles * (unsigned)p.nk;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvQ
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = (int)nslice * BN;
     // Tiles are filled by LDS-DMA (buffer_load_dwordx4 ... lds): one wave instruction writes 1 KB = 8 rows x 128 B of the
     // tile in lane order, so lane l of wave w owns PHYSICAL slot (l & 7) of rows 8w + (l >> 3) + RPI i and fetches the
     // LOGICAL chunk that the swizzle puts there (the swizzle goes on the source address); RPI is a multiple of 16, so
@@ -433,10 +433,8 @@ int launch_act(ConvQ p, hipStream_t st) {
     auto kernel = conv_igemm_kernel<T, OutT, BM, BN, WM, WN, NST, ACT>;
     p.ntiles = (p.M + BM - 1) / BM;
     const int gy = (p.Cout + BN - 1) / BN;
-    int gx = resident_blocks<T, OutT, BM, BN, WM, WN, NST, ACT>() / gy;
-    if (gx < 1) gx = 1;
-    if ((unsigned)gx > p.ntiles) gx = (int)p.ntiles;
-    hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(WM * WN * 64), 0, st, p);
+    const int gx = cc_grid_x(resident_blocks<T, OutT, BM, BN, WM, WN, NST, ACT>(), gy, p.ntiles);
+    hipLaunchKernelGGL(kernel, dim3(gx * gy), dim3(WM * WN * 64), 0, st, p);
     CC_LAUNCH_CHECK();
     return CCNET_OK;
 }

@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
     unsigned char* const patch0 = smem;
     unsigned char* const bt0 = smem + 2 * PATCH_BYTES;
 
-    unsigned tile0, tstride, tend;
-    cc_tile_walk(p.ntiles, p.xcd, tile0, tstride, tend);
+    unsigned tile0, tstride, tend, nslice;
+    cc_tile_walk_sliced(p.ntiles, p.xcd, (unsigned)((p.Cout + BN - 1) / BN), tile0, tstride, tend, nslice);
     if (tile0 >= tend) return;
     const unsigned my_tiles = (tend - tile0 + tstride - 1) / tstride;
     const unsigned total_chunks = my_tiles * (unsigned)p.nchunks;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchQ p) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = (int)nslice * BN;
 
     const __amdgpu_buffer_rsrc_t rsrcA0 = make_rsrc(p.seg[0].ptr, p.seg[0].span);
     const __amdgpu_buffer_rsrc_t rsrcA1 = make_rsrc(p.seg[1].ptr, p.seg[1].span);
@@ -524,10 +524,8 @@ int launch_patch_s2d(const PatchQ& p, hipStream_t st) {
         cached[dev] = per_cu * cus;
     }
     const int gy = (p.Cout + BN - 1) / BN;
-    int gx = cached[dev] / gy;
-    if (gx < 1) gx = 1;
-    if ((unsigned)gx > p.ntiles) gx = (int)p.ntiles;
-    hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(256), LDS, st, p);
+    const int gx = cc_grid_x(cached[dev], gy, p.ntiles);
+    hipLaunchKernelGGL(kernel, dim3(gx * gy), dim3(256), LDS, st, p);
     CC_LAUNCH_CHECK();
     return CCNET_OK;
 }
