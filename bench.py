@@ -367,7 +367,7 @@ def main():
     thin_gbs = thin_by / (thin_ms * 1e-3) / 1e9 if thin_ms > 0 else 0.0
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": None,
-                "kernel": "conv_halo_kernel (3x3 / SpaceToDepth layers) + conv_patch_kernel + conv_igemm_kernel, the %d MFMA-bound launches of one forward (>= %d FLOP/B)" % (len(hot), int(ridge)),
+                "kernel": "conv_halo_kernel (3x3 / SpaceToDepth layers) + bneck_fused_kernel (where taken) + conv_patch_kernel + conv_igemm_kernel, the %d MFMA-bound launches of one forward (>= %d FLOP/B)" % (len(hot), int(ridge)),
                 "avg_launch_us": round(hot_ms * 1e3 / max(len(hot), 1), 2), "flops_per_launch": hot_fl / max(len(hot), 1),
                 "ms_per_forward": round(hot_ms, 3),
                 "hbm_bound_launches": {"n": len(thin), "ms_per_forward": round(thin_ms, 3), "bound": "hbm", "achieved": round(thin_gbs, 1),

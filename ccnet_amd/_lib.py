@@ -48,6 +48,9 @@ def lib():
         L.ccnet_conv_pw_stream_elems.argtypes = [i32, i32]
         L.ccnet_conv_pw_stream_elems.restype = sz
         L.ccnet_conv_pw.argtypes = [C.POINTER(Slice), i32, i32, i32, i32, i32, vp, vp, i32, Slice, Slice, vp]
+        L.ccnet_bneck_fused_stream_elems.argtypes = [i32]
+        L.ccnet_bneck_fused_stream_elems.restype = sz
+        L.ccnet_bneck_fused.argtypes = [Slice, i32, i32, i32, vp, vp, vp, i32, i32, Slice, vp]
         L.ccnet_csp_fused_weight_elems.argtypes = [i32, i32]
         L.ccnet_csp_fused_weight_elems.restype = sz
         L.ccnet_csp_fused.argtypes = [C.POINTER(Slice), i32, i32, i32, i32, i32, i32, i32, vp, vp, Slice, vp]

@@ -367,6 +367,29 @@ class Compiler:
             return out
         cat = self.conv_w(torch.cat([w1, w2], 0), torch.cat([b1, b2], 0), ins, 1, 0, self.act)  # [x_1 | x_2]
         x1 = cat.part(0, h)
+        if self._bneck_fused_wins(h, x0.H, x0.W, amff):
+            # every Bottleneck (1x1 -> 3x3 [+ x]) in one launch with its hidden map in LDS (bneck_fused.hip).  Its results are
+            # bit-identical to the two launches, so this choice (which looks at the batch size) never shows in an output.  The
+            # kernel cannot work in place (a tile's halo is its neighbours' output): x_1 moves through scratch maps and, with two
+            # or more bottlenecks, ends where the separate launches leave it; a single bottleneck leaves it in a scratch map
+            # and conv3 reads [x_1 | x_2] as two segments -- the same k order as the concatenated buffer.
+            pong = [None, None]
+            cur = x1
+            for i in range(n):
+                q = "%s.m.%d" % (p, i)
+                wa, ba = self.folded(q + ".conv1")
+                wb, bb = self.folded(q + ".conv2")
+                pk = ops.PackedBneck(wa, ba, wb, bb, self.dev)
+                self.keep.append(pk)
+                if i == n - 1 and n >= 2:
+                    dst = x1
+                else:
+                    if pong[i & 1] is None:
+                        pong[i & 1] = self.new(h, x0.H, x0.W)
+                    dst = pong[i & 1]
+                ops.bneck_fused(cur.sl(), pk, self.B, x0.H, x0.W, shortcut, self.act, dst.sl())
+                cur = dst
+            return self.base_conv(p + ".conv3", [cat] if n >= 2 else [cur, cat.part(h, h)])
         for i in range(n):
             q = "%s.m.%d" % (p, i)
             if amff:
@@ -379,6 +402,20 @@ class Compiler:
                 t = self.base_conv(q + ".conv1", [x1])
                 self.base_conv(q + ".conv2", [t], out=x1, residual=x1 if shortcut else None)
         return self.base_conv(p + ".conv3", [cat])
+
+    def _bneck_fused_wins(self, h, H, W, amff):
+        """Where ccnet_bneck_fused beats conv1x1 + conv3x3 (same-box A/B, scripts/ab_env.sh and scripts/bneck_bench.py): 64 channels
+        always (two workgroups per CU: 37 against 47 us at 32 x 80^2, 63 against 78 at 64 x 80^2); 128 channels (96 KB of LDS: one
+        workgroup of four waves per CU) while every tile finds a CU of its own (31 against 36 us at 32 x 40^2, but 60 against 53
+        at 64 x 40^2, 431 tiles).  CCNET_NO_FUSED_BNECK=1 turns it off, CCNET_FUSED_BNECK_ALL=1 takes every 64 / 128-channel one."""
+        if (self.dtype != BF16 or amff or h not in (64, 128) or self.act != "silu"
+                or os.environ.get("CCNET_NO_FUSED_BNECK", "0") != "0"):
+            return False
+        if h == 64 or os.environ.get("CCNET_FUSED_BNECK_ALL", "0") != "0":
+            return True
+        lin = W + 2 <= 47 and (W + 2) * (H + 1) < ((W + 15) // 16) * ((H + 15) // 16) * 256     # bneck_fused.hip's geometry choice
+        tiles = ((self.B * (H + 1) + 1) * (W + 2) + 255) // 256 if lin else self.B * ((W + 15) // 16) * ((H + 15) // 16)
+        return tiles <= torch.cuda.get_device_properties(self.dev).multi_processor_count
 
     def sppf(self, p, x):
         w, b = self.folded(p + ".conv1")

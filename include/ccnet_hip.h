@@ -117,6 +117,20 @@ size_t ccnet_conv_pw_stream_elems(int Cin, int Cout);
 int ccnet_conv_pw(const ccnet_slice* in, int nseg, int B, int H, int W, int Cout, const void* wstream_dev, const float* bias_dev,
                   int act, ccnet_slice residual, ccnet_slice out, ccnet_stream stream);
 
+/* ---- one Bottleneck in one launch (bf16) ----------------------------------------------------------------------
+ * Replaces Bottleneck.forward as CSPLayer builds it (network/model_block.py:193-218 inside :86-116, expansion 1.0):
+ *   y = [x +] conv2(conv1(x)),  conv1 = BaseConv k1 (C -> C), conv2 = BaseConv k3 s1 p1 (C -> C), BN folded, SiLU, C = 64 or 128.
+ * The hidden map stays in LDS (ccnet_amd/csrc/bneck_fused.hip).  `in`: one un-shifted bf16 slice of C channels; `out`: C channels,
+ * must NOT overlap `in` (a tile's halo is its neighbours' output pixels) -- CCNET_EINVAL otherwise.  shortcut != 0 adds x after
+ * the activation.  wstream_dev: bf16, ccnet_bneck_fused_stream_elems(C) elements: for each block of 64 output channels of conv2,
+ * the C/32 x C/16 MFMA A-operand fragments of conv1 (k-step major, then 16-row n-tile; ALL output channels), then conv2's
+ * fragments in ccnet_conv_halo's order (32-channel chunk, tap, n-tile), then a copy of the block's first 8 (C = 64) or 16 (C = 128)
+ * fragments (ccnet_amd/ops.py:PackedBneck).  bias1_dev / bias2_dev: fp32[C].  Results are bit-identical to ccnet_conv2d (conv1) followed
+ * by ccnet_conv_halo (conv2).  Anything else: CCNET_EINVAL (callers use the two launches). */
+size_t ccnet_bneck_fused_stream_elems(int C);
+int ccnet_bneck_fused(ccnet_slice in, int B, int H, int W, const void* wstream_dev, const float* bias1_dev, const float* bias2_dev,
+                      int shortcut, int act, ccnet_slice out, ccnet_stream stream);
+
 /* ---- a whole CSPLayer with one bottleneck in one launch (bf16) ---------------------------------------------
  * Replaces CSPLayer.forward with n = 1 (network/model_block.py:86-116) and the Bottleneck inside it (:193-218):
  *   x_1 = conv1(x); x_2 = conv2(x); x_1 = [x_1 +] conv_b2(conv_b1(x_1)); out = conv3(cat(x_1, x_2))

@@ -18,7 +18,7 @@ for line in open(log):
 n = len(ops)
 
 def per_dispatch(path):
-    rows = [r for r in csv.DictReader(open(path)) if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv_patch", "conv_halo", "conv_pw", "conv_generic", "conv_stream", "csp_fused"))]
+    rows = [r for r in csv.DictReader(open(path)) if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv_patch", "conv_halo", "conv_pw", "conv_generic", "conv_stream", "csp_fused", "bneck_fused"))]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return [float(r["Counter_Value"]) * 1024.0 for r in rows]
 
@@ -44,7 +44,7 @@ for name, g in res.items():
 import os
 tr = prof + "/trace_serial/t_kernel_trace.csv"
 if os.path.exists(tr):
-    rows = [r for r in csv.DictReader(open(tr)) if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv_patch", "conv_halo", "conv_pw", "conv_generic", "conv_stream", "csp_fused"))]
+    rows = [r for r in csv.DictReader(open(tr)) if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv_patch", "conv_halo", "conv_pw", "conv_generic", "conv_stream", "csp_fused", "bneck_fused"))]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
     if len(dur) % n == 0:

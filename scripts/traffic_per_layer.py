@@ -8,7 +8,7 @@ for line in open(log):
     if m:
         ops.append((int(m.group(1)), m.group(2), float(m.group(3)), float(m.group(4)), float(m.group(5))))
 n = len(ops)
-K = ("conv_igemm", "conv_patch", "conv_halo", "conv_pw", "conv_generic", "conv_stream", "csp_fused")
+K = ("conv_igemm", "conv_patch", "conv_halo", "conv_pw", "conv_generic", "conv_stream", "csp_fused", "bneck_fused")
 def per(path):
     rows = [r for r in csv.DictReader(open(path)) if any(k in r["Kernel_Name"] for k in K)]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))

@@ -404,6 +404,89 @@ def test_conv_pw_equals_conv2d_bitwise_and_matches_torch(case):
     assert float(out[..., :4].float().abs().max()) == 0.0 and float(out[..., 4 + cout:].float().abs().max()) == 0.0   # neighbours untouched
 
 
+BNECK_CASES = [
+    # B, C, H, W, shortcut, in (ldc, coff), out (ldc, coff)
+    (3, 128, 40, 40, True, (256, 0), (128, 0)),      # dark4's bottlenecks: x_1 is the first half of [x_1 | x_2]; linear geometry
+    (2, 64, 80, 80, True, (128, 0), (64, 0)),        # net_deploy dark3: 16 x 16 tiles
+    (5, 128, 20, 20, False, (128, 0), (256, 128)),   # no shortcut (PAN), output into a slice of a wider buffer
+    (1, 64, 23, 37, True, (64, 0), (64, 0)),         # partial 16 x 16 tiles
+    (2, 128, 9, 30, True, (136, 8), (128, 0)),       # linear geometry with a partial last tile, input slice at a channel offset
+    (40, 64, 80, 80, True, (64, 0), (64, 0)),        # 1000 tiles on 512 workgroup slots: second tiles, the ring across the tile boundary
+    (48, 128, 40, 40, True, (128, 0), (128, 0)),     # 325 tiles on 256 slots, linear geometry
+]
+
+
+@pytest.mark.parametrize("case", BNECK_CASES)
+def test_bneck_fused_equals_the_two_launches_bitwise_and_matches_torch(case):
+    """ccnet_bneck_fused (1x1 -> 3x3 [+ x] with the hidden map in LDS) against ccnet_conv2d followed by ccnet_conv_halo on the same
+    operands: bit for bit (same MFMA shape, k order, bias placement, rounding points), and against torch (model_block.py:193-218)."""
+    ops = _ops()
+    B, Cc, H, W, shortcut, (ildc, icoff), (oldc, ocoff) = case
+    g = torch.Generator().manual_seed(7 + Cc + H)
+    x = torch.randn(B, Cc, H, W, generator=g)
+    w1 = torch.randn(Cc, Cc, 1, 1, generator=g) / math.sqrt(Cc)
+    b1 = torch.randn(Cc, generator=g) * 0.3          # SiLU(b1) != 0: rows outside the image must be zero, not conv1(0)
+    w2 = torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(9 * Cc)
+    b2 = torch.randn(Cc, generator=g) * 0.1
+    xt = to_nhwc(x, 1, ldc=ildc, coff=icoff)
+    xs = ops.sl(xt, icoff, Cc)
+    pk = ops.PackedBneck(w1, b1, w2, b2, DEV)
+    out = torch.zeros(B, H, W, oldc, dtype=torch.bfloat16, device=DEV)
+    ops.bneck_fused(xs, pk, B, H, W, shortcut, "silu", ops.sl(out, ocoff, Cc))
+    out2 = torch.zeros_like(out)
+    ops.bneck_fused(xs, pk, B, H, W, shortcut, "silu", ops.sl(out2, ocoff, Cc))
+    hid = torch.zeros(B, H, W, Cc, dtype=torch.bfloat16, device=DEV)
+    ref = torch.zeros(B, H, W, oldc, dtype=torch.bfloat16, device=DEV)
+    ops.conv2d([xs], ops.PackedConv(w1, b1, 1, DEV), B, H, W, 1, 0, ops.sl(hid), "silu")
+    ops.conv_halo([ops.sl(hid)], ops.PackedHalo(w2, b2, DEV), 0, B, H, W, ops.sl(ref, ocoff, Cc), "silu", xs if shortcut else None)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
+    h = q(F.silu(F.conv2d(q(x, 1), q(w1, 1), b1)), 1)
+    y = F.silu(F.conv2d(h, q(w2, 1), b2, padding=1))
+    if shortcut:
+        y = y + q(x, 1)
+    assert rel(from_nhwc(out, ocoff, Cc), y) < tol(1)
+    if oldc > Cc:
+        mask = torch.ones(oldc, dtype=torch.bool)
+        mask[ocoff:ocoff + Cc] = False
+        assert float(out[..., mask.to(DEV)].float().abs().max()) == 0.0   # neighbours untouched
+
+
+@pytest.mark.parametrize("cout,cin", [(256, 256), (128, 128), (256, 512)])
+def test_conv1x1_two_segments_equal_the_concatenated_buffer_bitwise(cout, cin):
+    """conv3 of a CSPLayer reads [x_1 | x_2] either as one buffer or as two segments (graph.py:csp with one fused bottleneck): the k
+    order is the same, so the results must be equal bit for bit, whichever 1x1 kernel the shape selects."""
+    ops = _ops()
+    from ccnet_amd.network import graph
+    B, H, W = 3, 20, 20
+    g = torch.Generator().manual_seed(5 + cout)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)
+    bias = torch.randn(cout, generator=g) * 0.1
+    whole = to_nhwc(x, 1)
+    a, b = whole[..., :cin // 2].contiguous(), whole[..., cin // 2:].contiguous()
+    comp = graph.Compiler({}, {}, B, H, W, 1, DEV, "silu")
+    one = comp.conv_w(w.double(), bias.double(), [graph.T(whole, 0, cin, H, W)], 1, 0, "silu")
+    two = comp.conv_w(w.double(), bias.double(), [graph.T(a, 0, cin // 2, H, W), graph.T(b, 0, cin // 2, H, W)], 1, 0, "silu")
+    torch.cuda.synchronize()
+    assert torch.equal(one.buf.view(torch.int16), two.buf.view(torch.int16))
+
+
+def test_bneck_fused_rejects_what_it_does_not_take():
+    ops = _ops()
+    pk = ops.PackedBneck(torch.zeros(64, 64, 1, 1), torch.zeros(64), torch.zeros(64, 64, 3, 3), torch.zeros(64), DEV)
+    x = torch.zeros(1, 8, 8, 128, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(Exception):
+        ops.bneck_fused(ops.sl(x, 0, 64), pk, 1, 8, 8, True, "silu", ops.sl(x, 0, 64))     # in place: a tile's halo is its neighbours' output
+    with pytest.raises(Exception):
+        ops.bneck_fused(ops.sl(x, 0, 64), pk, 1, 8, 8, True, "relu", ops.sl(x, 64, 64))    # SiLU only
+    with pytest.raises(Exception):
+        ops.bneck_fused(ops.sl(x, 0, 32), pk, 1, 8, 8, True, "silu", ops.sl(x, 64, 32))    # 32 channels
+    ops.bneck_fused(ops.sl(x, 0, 64), pk, 1, 8, 8, True, "silu", ops.sl(x, 64, 64))        # the other half of the same buffer is fine
+    torch.cuda.synchronize()
+
+
 def test_conv_pw_rejects_what_it_does_not_take():
     ops = _ops()
     with pytest.raises(Exception):
