@@ -20,6 +20,17 @@
 #include <mutex>
 #include "conv_common.h"
 
+#ifndef BK_ABL
+#define BK_ABL 0   // timing ablations (wrong results): 1 = no SiLU on h, 2 = no SiLU in the output epilogue, 4 = no ring refills, 8 = pixel fragments read once per tile, 16 = no x DMA for the second and later tiles
+#endif
+
+#ifdef BK_STAMP   // diagnostic build only: time (s_memtime ticks) block 0 spends per phase, summed over its tiles (scripts/bneck_bench.py)
+__device__ unsigned long long g_bk_stamps[8];
+#define BKSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_bk_stamps[i], n_ - st_last); st_last = n_; } } while (0)
+#else
+#define BKSTAMP(i)
+#endif
+
 namespace {
 
 constexpr int FROWB = 64;                 // bytes per plane row (32 channels)
@@ -69,12 +80,12 @@ struct BneckQ {
     {                                                                                                                              \
         constexpr int idx_ = (CC) * 9 + (TAP), cur_ = idx_ & 1, nidx_ = idx_ + 1;                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        if constexpr (nidx_ < NP * 9) { BK_LOAD(fa[cur_ ^ 1], smem + (nidx_ / 9) * FPLANE, nidx_ % 9) }                            \
+        if constexpr (nidx_ < NP * 9 && !(BK_ABL & 8)) { BK_LOAD(fa[cur_ ^ 1], smem + (nidx_ / 9) * FPLANE, nidx_ % 9) }           \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                                           \
             const int slot = ((CC) * 36 + (TAP) * NT + j) % FRING;                                                                 \
             _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                         \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[slot]), __builtin_bit_cast(bf16x8, fa[cur_][i]), acc[i][j], 0, 0, 0); \
-            ring[slot] = *(const u32x4*)(wp + FRING * 1024 + loff);                                                                \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[slot]), __builtin_bit_cast(bf16x8, fa[(BK_ABL & 8) ? 0 : cur_][i]), acc[i][j], 0, 0, 0); \
+            if (!(BK_ABL & 4)) ring[slot] = *(const u32x4*)(wp + FRING * 1024 + loff);                                             \
             wp += 1024;                                                                                                            \
         }                                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
@@ -188,6 +199,9 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
     TileAt ta = tile_at(tile0);
     fill_pixels(ta);
     issue_x();
+#ifdef BK_STAMP
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
 
     for (unsigned tile = tile0; tile < tend; tile += tstride) {
         __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): the planes (and the bias table) have landed
@@ -199,6 +213,7 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
             asm volatile("" : "+s"(wpo));
             wp = (const unsigned char*)wpo;
         }
+        BKSTAMP(0);
 
         // ---- phase 1: acc1[m][n] = W1 x over the rows of m-tiles wave + 4 m
         {
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
 #pragma unroll
                     for (int m = 0; m < MT1; ++m)
                         acc1[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[slot]), __builtin_bit_cast(bf16x8, fx[pl & 1][m]), acc1[m][n], 0, 0, 0);
-                    ring[slot] = *(const u32x4*)(wp + FRING * 1024 + loff);
+                    if (!(BK_ABL & 4)) ring[slot] = *(const u32x4*)(wp + FRING * 1024 + loff);
                     wp += 1024;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -233,6 +248,7 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
             __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): every wave's reads of x are done before h overwrites the planes
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            BKSTAMP(1);
 
             // ---- h = SiLU(acc1 + b1) as bf16 into the planes, zero outside the image
             float4 bv[NT1];
@@ -244,8 +260,9 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
                 const bool real = patch_pixel(ta, (wave + 4 * m) * 16 + fr) >= 0;
 #pragma unroll
                 for (int n = 0; n < NT1; ++n) {
-                    float v0 = act_fn<CCNET_ACT_SILU>(acc1[m][n][0] + bv[n].x), v1 = act_fn<CCNET_ACT_SILU>(acc1[m][n][1] + bv[n].y);
-                    float v2 = act_fn<CCNET_ACT_SILU>(acc1[m][n][2] + bv[n].z), v3 = act_fn<CCNET_ACT_SILU>(acc1[m][n][3] + bv[n].w);
+                    constexpr int A1 = (BK_ABL & 1) ? CCNET_ACT_NONE : CCNET_ACT_SILU;
+                    float v0 = act_fn<A1>(acc1[m][n][0] + bv[n].x), v1 = act_fn<A1>(acc1[m][n][1] + bv[n].y);
+                    float v2 = act_fn<A1>(acc1[m][n][2] + bv[n].z), v3 = act_fn<A1>(acc1[m][n][3] + bv[n].w);
                     uint2 h = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                     if (!real) h = make_uint2(0u, 0u);
                     *(uint2*)(smem + (n >> 1) * FPLANE + m * 4096 + (w1o ^ ((n & 1) * 32))) = h;
@@ -255,6 +272,7 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        BKSTAMP(2);
 
         // ---- phase 2: nine taps over the resident planes of h
         f32x4 acc[MT][NT];
@@ -276,6 +294,7 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): every wave's reads of h are done before the next x overwrites the planes
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        BKSTAMP(3);
 
         // ---- this tile's shortcut rows are requested, then the next tile's x, then the epilogue runs while both arrive (vector
         // memory returns in order: requested after the x planes, the shortcut rows would hold the epilogue back behind them)
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
             const TileAt tn = tile_at(tile + tstride);
             if (tn.valid) {
                 fill_pixels(tn);
-                issue_x();
+                if (!(BK_ABL & 16)) issue_x();
             }
             ta = tn;
 #pragma unroll
@@ -324,8 +343,9 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
                 float v[NT][4];
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    v[j][0] = act_fn<CCNET_ACT_SILU>(acc[i][j][0] + bv[j].x); v[j][1] = act_fn<CCNET_ACT_SILU>(acc[i][j][1] + bv[j].y);
-                    v[j][2] = act_fn<CCNET_ACT_SILU>(acc[i][j][2] + bv[j].z); v[j][3] = act_fn<CCNET_ACT_SILU>(acc[i][j][3] + bv[j].w);
+                    constexpr int A2 = (BK_ABL & 2) ? CCNET_ACT_NONE : CCNET_ACT_SILU;
+                    v[j][0] = act_fn<A2>(acc[i][j][0] + bv[j].x); v[j][1] = act_fn<A2>(acc[i][j][1] + bv[j].y);
+                    v[j][2] = act_fn<A2>(acc[i][j][2] + bv[j].z); v[j][3] = act_fn<A2>(acc[i][j][3] + bv[j].w);
                 }
                 if (p.shortcut) {   // added after the activation (model_block.py:213-218)
 #pragma unroll
@@ -338,6 +358,7 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
                 for (int j = 0; j < NT; ++j) *(uint2*)(orow + j * 32) = make_uint2(pack_bf16x2(v[j][0], v[j][1]), pack_bf16x2(v[j][2], v[j][3]));
             }
         }
+        BKSTAMP(4);
     }
 }
 
@@ -375,6 +396,18 @@ void bneck_magic(unsigned d, unsigned* magic, unsigned* shift) {
 }
 
 }  // namespace
+
+#ifdef BK_STAMP
+extern "C" int ccnet_debug_bneck_stamps(unsigned long long* out8, int reset) {
+    CC_HIP(hipDeviceSynchronize());
+    CC_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bk_stamps), sizeof(unsigned long long) * 8));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        CC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bk_stamps), z, sizeof(z)));
+    }
+    return CCNET_OK;
+}
+#endif
 
 extern "C" size_t ccnet_bneck_fused_stream_elems(int C) {
     if (C != 64 && C != 128) return 0;

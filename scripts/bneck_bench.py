@@ -4,7 +4,7 @@ from scripts/ab_env.sh CCNET_NO_FUSED_BNECK=1."""
 import math, sys, torch
 sys.path.insert(0, ".")
 from ccnet_amd import ops
-from ccnet_amd._lib import sl
+from ccnet_amd._lib import lib, sl
 
 DEV = "cuda"
 def bench(fn, n=60):
@@ -31,3 +31,12 @@ for B, C, H in [(64, 128, 40), (32, 128, 40), (32, 64, 80), (64, 64, 80), (16, 1
     tf, tu = bench(f), bench(u)
     tf2, tu2 = bench(f), bench(u)
     print("B %3d C %3d %dx%d: fused %.1f / %.1f us   two launches %.1f / %.1f us" % (B, C, H, H, tf, tf2, tu, tu2), flush=True)
+    L = lib()
+    if hasattr(L, "ccnet_debug_bneck_stamps"):   # -DBK_STAMP build: ticks (10 ns) block 0 spends per phase, per launch
+        import ctypes
+        buf = (ctypes.c_ulonglong * 8)()
+        L.ccnet_debug_bneck_stamps(buf, 1)
+        for _ in range(20): f()
+        L.ccnet_debug_bneck_stamps(buf, 1)
+        names = ["wait x", "phase 1", "h epilogue", "phase 2", "out epilogue"]
+        print("     block 0 per launch: " + "  ".join("%s %.2f us" % (n, buf[i] / 20 * 0.01) for i, n in enumerate(names)), flush=True)
