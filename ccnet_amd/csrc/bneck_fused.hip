@@ -34,13 +34,16 @@ __device__ unsigned long long g_bk_stamps[8];
 namespace {
 
 constexpr int FROWB = 64;                 // bytes per plane row (32 channels)
-constexpr int FPIECES = 22;               // LDS-DMA pieces (16 rows) per plane
-constexpr int FPROWS = FPIECES * 16;      // 352 >= 18 * 18 (2D) and >= 256 + 2 * 47 + 2 (LIN)
-constexpr int FPLANE = FPROWS * FROWB;    // 22528
 constexpr int FLINMAXWP = 47;
-// weight fragments in flight per wave.  C = 128 runs one workgroup per CU (96 KB of LDS), i.e. one wave per SIMD with nobody to cover a
-// late fragment, and has the registers: 16.  C = 64 runs two: 8.
-constexpr int bneck_ring(int C) { return C == 128 ? 16 : 8; }
+// LDS-DMA pieces (16 rows) per plane: 22 = 352 rows >= 18 * 18 (16 x 16 tiles) and >= 256 + 2 * 47 + 2 (256 linear positions).
+// C = 256 (the 20 x 20 maps) works on tiles of 128 linear positions, 11 pieces = 176 rows >= 128 + 2 * 23 + 2, so that its eight
+// planes are the same 88 KB: one workgroup per CU either way.
+constexpr int bneck_pieces(int C) { return C == 256 ? 11 : 22; }
+constexpr int bneck_tile_px(int C) { return C == 256 ? 128 : 256; }
+constexpr int FLINMAXWP256 = 23;
+// weight fragments in flight per wave.  C >= 128 runs one workgroup per CU (96 KB of LDS), i.e. one wave per SIMD with nobody to cover
+// a late fragment, and has the registers: 16.  C = 64 runs two: 8.
+constexpr int bneck_ring(int C) { return C >= 128 ? 16 : 8; }
 
 struct BneckQ {
     const unsigned char* in_ptr;   // first element of the x slice
@@ -50,7 +53,7 @@ struct BneckQ {
     int Wp, Hp;                    // LIN: padded width W + 2, rows per image H + 1
     unsigned magicWp, shiftWp, magicHp, shiftHp;
     unsigned ntiles;
-    const unsigned char* wstream;  // [C / 64][F1 + (C / 32) * 36 + bneck_ring(C)][64 lanes][16 B]
+    const unsigned char* wstream;  // [C / 64][(C / 32) * (C / 16) + (C / 32) * 36 + bneck_ring(C)][64 lanes][16 B]
     unsigned long long wstride;
     const float* bias1;
     const float* bias2;
@@ -74,13 +77,14 @@ struct BneckQ {
         }                                                                                                                          \
     }
 
-// tap TAP of plane CC: the NEXT tap's pixel fragments are requested first (one wave per SIMD at C = 128: nothing else hides the
-// LDS latency), then NT x MT MFMAs on the fragments requested a tap ago
+// tap TAP of plane CC of the current group of planes (at pt): the NEXT tap's pixel fragments are requested first (one wave per
+// SIMD at C >= 128: nothing else hides the LDS latency), then NT x MT MFMAs on the fragments requested a tap ago
 #define BK_TAP(CC, TAP)                                                                                                            \
     {                                                                                                                              \
         constexpr int idx_ = (CC) * 9 + (TAP), cur_ = idx_ & 1, nidx_ = idx_ + 1;                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                                         \
-        if constexpr (nidx_ < NP * 9 && !(BK_ABL & 8)) { BK_LOAD(fa[cur_ ^ 1], smem + (nidx_ / 9) * FPLANE, nidx_ % 9) }           \
+        if constexpr (nidx_ < PG * 9 && !(BK_ABL & 8)) { BK_LOAD(fa[cur_ ^ 1], pt + (nidx_ / 9) * PLANE, nidx_ % 9) }              \
+        else if constexpr (NG > 1 && !(BK_ABL & 8)) { BK_LOAD(fa[cur_ ^ 1], ptn, 0) }                                              \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                                           \
             const int slot = ((CC) * 36 + (TAP) * NT + j) % FRING;                                                                 \
             _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                         \
@@ -93,18 +97,22 @@ struct BneckQ {
 
 template <int C, bool LIN>
 __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(const BneckQ p) {
+    static_assert(C != 256 || LIN, "256 channels: linear tiles only");
     constexpr int NP = C / 32;             // planes
+    constexpr int PIECES = bneck_pieces(C), PLANE = PIECES * 16 * FROWB, TPX = bneck_tile_px(C);
+    constexpr int NPI = (PIECES + 3) / 4;  // pieces (and m-tiles of the 1x1) per wave: 22 over four waves = 6, 6, 5, 5; 11 = 3, 3, 3, 2
     constexpr int NT1 = C / 16;            // n-tiles of the 1x1: every wave computes all of them for its rows
-    constexpr int MT1 = 6;                 // patch m-tiles per wave (22 over four waves: 6, 6, 5, 5)
-    constexpr int MT = C == 128 ? 8 : 4, NT = 4;
+    constexpr int MT1 = NPI;
+    constexpr int MT = C == 64 ? 4 : 8, NT = 4;   // wave tile of the 3x3: 64 x 64 (C = 64), 128 x 64
     constexpr int PXW = MT * 16;
     constexpr int MSTR = LIN ? 16 * FROWB : 18 * FROWB;
     constexpr int F1 = NP * NT1;           // fragments of the 1x1 per tile
     constexpr int FRING = bneck_ring(C);
-    static_assert(F1 % FRING == 0 && (NP * 36) % FRING == 0, "ring slots are compile-time constants");
+    constexpr int PG = NP < 4 ? NP : 4, NG = NP / PG;   // the 3x3 walks the planes in groups of PG (unrolled), NG groups
+    static_assert(F1 % FRING == 0 && (PG * 36) % FRING == 0 && (PG * 9) % 2 == 0, "ring slots are compile-time constants");
     extern __shared__ __align__(16) unsigned char smem[];   // planes[NP] | pixtab | bias1 | bias2
-    int* pixtab = (int*)(smem + NP * FPLANE);
-    float* b1s = (float*)(smem + NP * FPLANE + 6 * 256 * 4);
+    int* pixtab = (int*)(smem + NP * PLANE);
+    float* b1s = (float*)(smem + NP * PLANE + NPI * 256 * 4);
     float* b2s = b1s + C;
 
     unsigned tile0, tstride, tend;
@@ -113,14 +121,15 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = C == 128 ? (wave >> 1) : wave, wn = C == 128 ? (wave & 1) : 0;
+    // waves over (pixels, 64-channel slices of the 3x3's output): 4 x 1 (C = 64), 2 x 2 (128), 1 x 4 (256)
+    const int wm = C == 64 ? wave : C == 128 ? (wave >> 1) : 0, wn = C == 64 ? 0 : C == 128 ? (wave & 1) : wave;
     const int fr = lane & 15, fq = lane >> 4;
 
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.in_ptr, p.in_span);
     constexpr unsigned OOB = 0x80000000u;
     const unsigned ldcB = p.in_ldcB;
 
-    if (t < C) { b1s[t] = p.bias1[t]; b2s[t] = p.bias2[t]; }
+    for (int c = t; c < C; c += 256) { b1s[c] = p.bias1[c]; b2s[c] = p.bias2[c]; }
 
     // ---- geometry (conv_halo.hip)
     const unsigned prc = (unsigned)(((lane & 3) ^ ((lane >> 3) & 3)) * 16);
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
     auto patch_pixel = [&](const TileAt& ta, int r) -> int {
         if (!ta.valid) return -1;
         if constexpr (LIN) {
-            return r < 256 + 2 * p.Wp + 2 ? lin_pixel(ta.tile * 256 - p.Wp - 1 + r) : -1;
+            return r < TPX + 2 * p.Wp + 2 ? lin_pixel(ta.tile * TPX - p.Wp - 1 + r) : -1;
         } else {
             const int py = r / 18, px = r - py * 18;
             const int vy = ta.y0 + py, vx = ta.x0 + px;
@@ -157,21 +166,21 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
     // a lane reads back only what it wrote itself: no barrier around the table
     auto fill_pixels = [&](const TileAt& ta) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < NPI; ++i) {
             const int pc = wave + 4 * i;
-            if (pc < FPIECES) pixtab[i * 256 + t] = patch_pixel(ta, 16 * pc + (lane >> 2));
+            if (pc < PIECES) pixtab[i * 256 + t] = patch_pixel(ta, 16 * pc + (lane >> 2));
         }
     };
     auto issue_x = [&]() {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < NPI; ++i) {
             const int pc = wave + 4 * i;
-            if (pc >= FPIECES) continue;   // wave uniform
+            if (pc >= PIECES) continue;   // wave uniform
             const int px = pixtab[i * 256 + t];
             const unsigned v = px >= 0 ? (unsigned)px * ldcB + prc : OOB;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + pl * FPLANE + pc * 1024), 16, (int)v, pl * 64, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + pl * PLANE + pc * 1024), 16, (int)v, pl * 64, 0, 0);
         }
     };
 
@@ -230,13 +239,13 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
                 __builtin_amdgcn_sched_barrier(0);
                 if (pl + 1 < NP) {
 #pragma unroll
-                    for (int m = 0; m < MT1; ++m) fx[(pl + 1) & 1][m] = *(const u32x4*)(smem + (pl + 1) * FPLANE + a1 + m * 4096);
+                    for (int m = 0; m < MT1; ++m) fx[(pl + 1) & 1][m] = *(const u32x4*)(smem + (pl + 1) * PLANE + a1 + m * 4096);
                 }
 #pragma unroll
                 for (int n = 0; n < NT1; ++n) {
                     const int slot = (pl * NT1 + n) % FRING;
-                    // (waves 2 and 3 own five m-tiles; their sixth multiplies whatever lies behind the plane -- still inside this
-                    // workgroup's LDS -- and is dropped below: cheaper than 32 branches)
+                    // (the waves that own one m-tile less multiply whatever lies behind the plane -- still inside this workgroup's
+                    // LDS -- and drop it below: cheaper than a branch per fragment)
 #pragma unroll
                     for (int m = 0; m < MT1; ++m)
                         acc1[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[slot]), __builtin_bit_cast(bf16x8, fx[pl & 1][m]), acc1[m][n], 0, 0, 0);
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
             for (int n = 0; n < NT1; ++n) bv[n] = *(const float4*)(b1s + n * 16 + fq * 4);
 #pragma unroll
             for (int m = 0; m < MT1; ++m) {
-                if (wave + 4 * m >= FPIECES) break;   // wave uniform: waves 2 and 3 own five m-tiles
+                if (wave + 4 * m >= PIECES) break;   // wave uniform: the last waves own one m-tile less
                 const bool real = patch_pixel(ta, (wave + 4 * m) * 16 + fr) >= 0;
 #pragma unroll
                 for (int n = 0; n < NT1; ++n) {
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
                     float v2 = act_fn<A1>(acc1[m][n][2] + bv[n].z), v3 = act_fn<A1>(acc1[m][n][3] + bv[n].w);
                     uint2 h = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                     if (!real) h = make_uint2(0u, 0u);
-                    *(uint2*)(smem + (n >> 1) * FPLANE + m * 4096 + (w1o ^ ((n & 1) * 32))) = h;
+                    *(uint2*)(smem + (n >> 1) * PLANE + m * 4096 + (w1o ^ ((n & 1) * 32))) = h;
                 }
             }
         }
@@ -283,11 +292,16 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
         {
             u32x4 fa[2][MT];
             BK_LOAD(fa[0], smem, 0)
-            BK_TAP(0, 0) BK_TAP(0, 1) BK_TAP(0, 2) BK_TAP(0, 3) BK_TAP(0, 4) BK_TAP(0, 5) BK_TAP(0, 6) BK_TAP(0, 7) BK_TAP(0, 8)
-            BK_TAP(1, 0) BK_TAP(1, 1) BK_TAP(1, 2) BK_TAP(1, 3) BK_TAP(1, 4) BK_TAP(1, 5) BK_TAP(1, 6) BK_TAP(1, 7) BK_TAP(1, 8)
-            if constexpr (NP == 4) {
-                BK_TAP(2, 0) BK_TAP(2, 1) BK_TAP(2, 2) BK_TAP(2, 3) BK_TAP(2, 4) BK_TAP(2, 5) BK_TAP(2, 6) BK_TAP(2, 7) BK_TAP(2, 8)
-                BK_TAP(3, 0) BK_TAP(3, 1) BK_TAP(3, 2) BK_TAP(3, 3) BK_TAP(3, 4) BK_TAP(3, 5) BK_TAP(3, 6) BK_TAP(3, 7) BK_TAP(3, 8)
+            for (int g = 0; g < NG; ++g) {
+                const unsigned char* pt = smem + g * PG * PLANE;
+                const unsigned char* ptn = smem + (g + 1 < NG ? g + 1 : 0) * PG * PLANE;
+                (void)ptn;
+                BK_TAP(0, 0) BK_TAP(0, 1) BK_TAP(0, 2) BK_TAP(0, 3) BK_TAP(0, 4) BK_TAP(0, 5) BK_TAP(0, 6) BK_TAP(0, 7) BK_TAP(0, 8)
+                BK_TAP(1, 0) BK_TAP(1, 1) BK_TAP(1, 2) BK_TAP(1, 3) BK_TAP(1, 4) BK_TAP(1, 5) BK_TAP(1, 6) BK_TAP(1, 7) BK_TAP(1, 8)
+                if constexpr (PG == 4) {
+                    BK_TAP(2, 0) BK_TAP(2, 1) BK_TAP(2, 2) BK_TAP(2, 3) BK_TAP(2, 4) BK_TAP(2, 5) BK_TAP(2, 6) BK_TAP(2, 7) BK_TAP(2, 8)
+                    BK_TAP(3, 0) BK_TAP(3, 1) BK_TAP(3, 2) BK_TAP(3, 3) BK_TAP(3, 4) BK_TAP(3, 5) BK_TAP(3, 6) BK_TAP(3, 7) BK_TAP(3, 8)
+                }
             }
         }
         wp -= wrewind;   // the stream ends with a copy of its first FRING fragments: the ring already holds the next tile's
@@ -316,7 +330,7 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 if constexpr (LIN) {
-                    mpix[i] = lin_pixel((int)tile * 256 + wm * PXW + i * 16 + fr);
+                    mpix[i] = lin_pixel((int)tile * TPX + wm * PXW + i * 16 + fr);
                 } else {
                     const int oy = ty * 16 + wm * MT + i, ox = tx * 16 + fr;
                     mpix[i] = (oy < p.H && ox < p.W) ? ((int)b * p.H + oy) * p.W + ox : -1;
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void bneck_fused_kernel(con
 template <int C, bool LIN>
 int launch_bneck(const BneckQ& p, hipStream_t st) {
     auto kernel = bneck_fused_kernel<C, LIN>;
-    constexpr int LDS = (C / 32) * FPLANE + 6 * 256 * 4 + 2 * C * 4;
+    constexpr int LDS = (C / 32) * bneck_pieces(C) * 16 * FROWB + ((bneck_pieces(C) + 3) / 4) * 256 * 4 + 2 * C * 4;
     static std::mutex mu;
     static int cached[16] = {0};
     int dev = 0;
@@ -410,7 +424,7 @@ extern "C" int ccnet_debug_bneck_stamps(unsigned long long* out8, int reset) {
 #endif
 
 extern "C" size_t ccnet_bneck_fused_stream_elems(int C) {
-    if (C != 64 && C != 128) return 0;
+    if (C != 64 && C != 128 && C != 256) return 0;
     return (size_t)(C / 64) * ((size_t)(C / 32) * (C / 16) + (size_t)(C / 32) * 36 + bneck_ring(C)) * 512;
 }
 
@@ -420,7 +434,8 @@ extern "C" int ccnet_bneck_fused(ccnet_slice in, int B, int H, int W, const void
     CC_REQUIRE(B > 0 && H > 0 && W > 0, "bneck_fused: bad sizes (B=%d H=%d W=%d)", B, H, W);
     CC_REQUIRE(act == CCNET_ACT_SILU, "bneck_fused: SiLU only (act=%d)", act);
     const int Cc = in.C;
-    CC_REQUIRE(Cc == 64 || Cc == 128, "bneck_fused: 64 or 128 channels (C=%d)", Cc);
+    CC_REQUIRE(Cc == 64 || Cc == 128 || Cc == 256, "bneck_fused: 64, 128 or 256 channels (C=%d)", Cc);
+    CC_REQUIRE(Cc != 256 || W + 2 <= FLINMAXWP256, "bneck_fused: 256 channels on maps up to %d wide only (W=%d)", FLINMAXWP256 - 2, W);
     CC_REQUIRE(cc_slice_vec_ok(in, CCNET_BF16) && in.shift == 0, "bneck_fused: input slice must be bf16, un-shifted, 16-byte aligned (C=%d ldc=%d coff=%d)",
                in.C, in.ldc, in.coff);
     CC_REQUIRE(((uintptr_t)wstream_dev % 16) == 0 && ((uintptr_t)bias1_dev % 16) == 0 && ((uintptr_t)bias2_dev % 16) == 0,
@@ -448,12 +463,13 @@ extern "C" int ccnet_bneck_fused(ccnet_slice in, int B, int H, int W, const void
     const int tx = (W + 15) / 16, ty = (H + 15) / 16;
     const double waste2d = (double)tx * ty * 256.0 / ((double)H * W);
     const double wastelin = (double)(W + 2) * (H + 1) / ((double)H * W);
-    const bool lin = W + 2 <= FLINMAXWP && wastelin < waste2d;
+    const bool lin = Cc == 256 || (W + 2 <= FLINMAXWP && wastelin < waste2d);
     if (lin) {
         p.Wp = W + 2; p.Hp = H + 1;
         const long long q = ((long long)B * p.Hp + 1) * p.Wp;
         CC_REQUIRE(q < (1ll << 30), "bneck_fused: too many padded positions");
-        p.ntiles = (unsigned)((q + 255) / 256);
+        const int tpx = bneck_tile_px(Cc);
+        p.ntiles = (unsigned)((q + tpx - 1) / tpx);
         bneck_magic((unsigned)p.Wp, &p.magicWp, &p.shiftWp);
         bneck_magic((unsigned)p.Hp, &p.magicHp, &p.shiftHp);
     } else {
@@ -471,6 +487,7 @@ extern "C" int ccnet_bneck_fused(ccnet_slice in, int B, int H, int W, const void
     const double bytes = (double)M * Cc * 4.0 + 10.0 * Cc * Cc * 2.0;
     return ccnet_submit(
         [p, lin, Cc](hipStream_t st, const float*) -> int {
+            if (Cc == 256) return launch_bneck<256, true>(p, st);
             if (Cc == 128) return lin ? launch_bneck<128, true>(p, st) : launch_bneck<128, false>(p, st);
             return lin ? launch_bneck<64, true>(p, st) : launch_bneck<64, false>(p, st);
         },

@@ -405,16 +405,21 @@ class Compiler:
 
     def _bneck_fused_wins(self, h, H, W, amff):
         """Where ccnet_bneck_fused beats conv1x1 + conv3x3 (same-box A/B, scripts/ab_env.sh and scripts/bneck_bench.py): 64 channels
-        always (two workgroups per CU: 37 against 47 us at 32 x 80^2, 63 against 78 at 64 x 80^2); 128 channels (96 KB of LDS: one
-        workgroup of four waves per CU) while every tile finds a CU of its own (31 against 36 us at 32 x 40^2, but 60 against 53
-        at 64 x 40^2, 431 tiles).  CCNET_NO_FUSED_BNECK=1 turns it off, CCNET_FUSED_BNECK_ALL=1 takes every 64 / 128-channel one."""
-        if (self.dtype != BF16 or amff or h not in (64, 128) or self.act != "silu"
+        always (two workgroups per CU: 37 against 47 us at 32 x 80^2, 63 against 78 at 64 x 80^2); 128 and 256 channels (96 KB of
+        LDS: one workgroup of four waves per CU, every SiLU exposed) while every tile finds a CU of its own (128: 31 against 36 us
+        at 32 x 40^2, but 60 against 53 at 64 x 40^2, 431 tiles).  CCNET_NO_FUSED_BNECK=1 turns it off, CCNET_FUSED_BNECK_ALL=1 takes
+        every shape the kernel has."""
+        if (self.dtype != BF16 or amff or h not in (64, 128, 256) or self.act != "silu"
                 or os.environ.get("CCNET_NO_FUSED_BNECK", "0") != "0"):
+            return False
+        if h == 256 and W + 2 > 23:        # bneck_fused.hip: 128-position linear tiles, maps up to 21 wide
             return False
         if h == 64 or os.environ.get("CCNET_FUSED_BNECK_ALL", "0") != "0":
             return True
-        lin = W + 2 <= 47 and (W + 2) * (H + 1) < ((W + 15) // 16) * ((H + 15) // 16) * 256     # bneck_fused.hip's geometry choice
-        tiles = ((self.B * (H + 1) + 1) * (W + 2) + 255) // 256 if lin else self.B * ((W + 15) // 16) * ((H + 15) // 16)
+        # bneck_fused.hip's geometry choice
+        lin = h == 256 or (W + 2 <= 47 and (W + 2) * (H + 1) < ((W + 15) // 16) * ((H + 15) // 16) * 256)
+        tpx = 128 if h == 256 else 256
+        tiles = ((self.B * (H + 1) + 1) * (W + 2) + tpx - 1) // tpx if lin else self.B * ((W + 15) // 16) * ((H + 15) // 16)
         return tiles <= torch.cuda.get_device_properties(self.dev).multi_processor_count
 
     def sppf(self, p, x):

@@ -190,18 +190,18 @@ def conv_pw(ins, pk, B, H, W, out, act="none", residual=None):
                               ACT[act], null_slice() if residual is None else residual, out, stream_ptr()))
 
 
-BNECK_RING = {64: 8, 128: 16}  # bneck_fused.hip: bneck_ring(C)
+BNECK_RING = {64: 8, 128: 16, 256: 16}  # bneck_fused.hip: bneck_ring(C)
 
 
 class PackedBneck:
-    """Register-stream packing of one Bottleneck (1x1 C->C, 3x3 C->C, C = 64 or 128) for ccnet_bneck_fused (include/ccnet_hip.h):
+    """Register-stream packing of one Bottleneck (1x1 C->C, 3x3 C->C, C = 64, 128 or 256) for ccnet_bneck_fused (include/ccnet_hip.h):
     w1 (C, C[, 1, 1]), w2 (C, C, 3, 3) fp64, BN folded."""
 
     def __init__(self, w1, b1, w2, b2, device):
         w1 = w1.to(torch.float64).reshape(w1.shape[0], -1)
         w2 = w2.to(torch.float64)
         c = w1.shape[0]
-        assert c in (64, 128) and tuple(w1.shape) == (c, c) and tuple(w2.shape) == (c, c, 3, 3)
+        assert c in (64, 128, 256) and tuple(w1.shape) == (c, c) and tuple(w2.shape) == (c, c, 3, 3)
         self.c = c
         # conv1: [nt][row][ks][kq][e] -> [ks][nt][kq][row][e]; a fragment is [kq (lane >> 4)][row (lane & 15)][8]
         f1 = w1.reshape(c // 16, 16, c // 32, 4, 8).permute(2, 0, 3, 1, 4).reshape(1, -1, 512).expand(c // 64, -1, -1)
@@ -213,12 +213,6 @@ class PackedBneck:
         self.weight = f.to(torch.bfloat16).to(device).contiguous()
         self.bias1 = b1.to(torch.float32).to(device).contiguous()
         self.bias2 = b2.to(torch.float32).to(device).contiguous()
-
-
-def bneck_fused_ok(dtype, x, out):
-    """Shapes ccnet_bneck_fused takes (the C entry point validates again; it also refuses an output that overlaps the input)."""
-    return (dtype == BF16 and x.C in (64, 128) and x.shift == 0 and x.ldc % 8 == 0 and x.coff % 8 == 0 and out.C == x.C
-            and out.ldc % 4 == 0 and out.coff % 4 == 0)
 
 
 def bneck_fused(x, pk, B, H, W, shortcut, act, out):

@@ -119,12 +119,13 @@ int ccnet_conv_pw(const ccnet_slice* in, int nseg, int B, int H, int W, int Cout
 
 /* ---- one Bottleneck in one launch (bf16) ----------------------------------------------------------------------
  * Replaces Bottleneck.forward as CSPLayer builds it (network/model_block.py:193-218 inside :86-116, expansion 1.0):
- *   y = [x +] conv2(conv1(x)),  conv1 = BaseConv k1 (C -> C), conv2 = BaseConv k3 s1 p1 (C -> C), BN folded, SiLU, C = 64 or 128.
+ *   y = [x +] conv2(conv1(x)),  conv1 = BaseConv k1 (C -> C), conv2 = BaseConv k3 s1 p1 (C -> C), BN folded, SiLU, C = 64, 128 or 256
+ *   (256: maps up to 21 wide).
  * The hidden map stays in LDS (ccnet_amd/csrc/bneck_fused.hip).  `in`: one un-shifted bf16 slice of C channels; `out`: C channels,
  * must NOT overlap `in` (a tile's halo is its neighbours' output pixels) -- CCNET_EINVAL otherwise.  shortcut != 0 adds x after
  * the activation.  wstream_dev: bf16, ccnet_bneck_fused_stream_elems(C) elements: for each block of 64 output channels of conv2,
  * the C/32 x C/16 MFMA A-operand fragments of conv1 (k-step major, then 16-row n-tile; ALL output channels), then conv2's
- * fragments in ccnet_conv_halo's order (32-channel chunk, tap, n-tile), then a copy of the block's first 8 (C = 64) or 16 (C = 128)
+ * fragments in ccnet_conv_halo's order (32-channel chunk, tap, n-tile), then a copy of the block's first 8 (C = 64) or 16 (C >= 128)
  * fragments (ccnet_amd/ops.py:PackedBneck).  bias1_dev / bias2_dev: fp32[C].  Results are bit-identical to ccnet_conv2d (conv1) followed
  * by ccnet_conv_halo (conv2).  Anything else: CCNET_EINVAL (callers use the two launches). */
 size_t ccnet_bneck_fused_stream_elems(int C);

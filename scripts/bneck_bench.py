@@ -16,7 +16,7 @@ def bench(fn, n=60):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 
-for B, C, H in [(64, 128, 40), (32, 128, 40), (32, 64, 80), (64, 64, 80), (16, 128, 80)]:
+for B, C, H in [(64, 128, 40), (32, 128, 40), (32, 64, 80), (64, 64, 80), (16, 128, 80), (64, 256, 20), (32, 256, 20)]:
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, H, H, C, generator=g).to(DEV).to(torch.bfloat16)
     w1 = torch.randn(C, C, 1, 1, generator=g) / math.sqrt(C); b1 = torch.randn(C, generator=g) * 0.1

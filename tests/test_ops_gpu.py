@@ -413,6 +413,10 @@ BNECK_CASES = [
     (2, 128, 9, 30, True, (136, 8), (128, 0)),       # linear geometry with a partial last tile, input slice at a channel offset
     (40, 64, 80, 80, True, (64, 0), (64, 0)),        # 1000 tiles on 512 workgroup slots: second tiles, the ring across the tile boundary
     (48, 128, 40, 40, True, (128, 0), (128, 0)),     # 325 tiles on 256 slots, linear geometry
+    (4, 256, 20, 20, True, (512, 0), (256, 0)),      # 256 channels: tiles of 128 linear positions, eight planes
+    (64, 256, 20, 20, False, (256, 0), (256, 0)),    # ... 232 tiles, no shortcut
+    (140, 256, 20, 20, True, (256, 0), (256, 0)),    # ... 506 tiles on 256 slots
+    (3, 256, 13, 21, True, (256, 0), (512, 256)),    # ... the widest map it takes, output at a channel offset
 ]
 
 
@@ -483,6 +487,10 @@ def test_bneck_fused_rejects_what_it_does_not_take():
         ops.bneck_fused(ops.sl(x, 0, 64), pk, 1, 8, 8, True, "relu", ops.sl(x, 64, 64))    # SiLU only
     with pytest.raises(Exception):
         ops.bneck_fused(ops.sl(x, 0, 32), pk, 1, 8, 8, True, "silu", ops.sl(x, 64, 32))    # 32 channels
+    pk256 = ops.PackedBneck(torch.zeros(256, 256, 1, 1), torch.zeros(256), torch.zeros(256, 256, 3, 3), torch.zeros(256), DEV)
+    x256 = torch.zeros(1, 8, 24, 256, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(Exception):
+        ops.bneck_fused(ops.sl(x256), pk256, 1, 8, 24, True, "silu", ops.sl(x256.clone()))  # 256 channels on a map wider than 21
     ops.bneck_fused(ops.sl(x, 0, 64), pk, 1, 8, 8, True, "silu", ops.sl(x, 64, 64))        # the other half of the same buffer is fine
     torch.cuda.synchronize()
 
