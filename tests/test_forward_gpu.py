@@ -201,6 +201,27 @@ def test_full_size_batch_independence_net_deploy():
             assert torch.equal(a[i:i + 1], b), "image %d level %d differs between bs%d and bs1" % (i, lvl, B)
 
 
+@pytest.mark.parametrize("kind,B,size", [("net_deploy", 4, 320), ("net", 3, 320), ("net_small_target", 2, 320)])
+def test_fused_bottleneck_choice_never_shows_in_an_output(kind, B, size, monkeypatch):
+    """graph.py takes ccnet_bneck_fused by layer shape AND batch size (it wins while every tile finds a CU of its own): allowed only
+    because its results are bit-identical to the two launches it replaces.  Whole networks built with the fused kernel everywhere
+    it exists, with the default rule and with it switched off must agree bit for bit (bf16)."""
+    from ccnet_amd import synth
+    x = synth.synth_images(B, size, size, seed=3).to("cuda")
+    outs = []
+    for env in ({"CCNET_NO_FUSED_BNECK": "1"}, {}, {"CCNET_FUSED_BNECK_ALL": "1"}):
+        monkeypatch.delenv("CCNET_NO_FUSED_BNECK", raising=False)
+        monkeypatch.delenv("CCNET_FUSED_BNECK_ALL", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = _model(kind, 0.33, 0.5, 6, "bf16")     # the plan is compiled at the first call, under this environment
+        outs.append([o.clone() for o in net(x)])
+        torch.cuda.synchronize()
+    for other in outs[1:]:
+        for lvl, (a, b) in enumerate(zip(outs[0], other)):
+            assert torch.equal(a, b), "level %d differs between the fused and the two-launch bottlenecks" % lvl
+
+
 @pytest.mark.parametrize("kind,depth,width,nc,act,size", [
     ("net", 1.0, 1.0, 80, "silu", 96),          # constructor defaults (l size, 80 classes): d_model 512 -> per-op Transformer path
     ("net_deploy", 0.67, 0.75, 20, "relu", 128),  # m size, ReLU epilogues
