@@ -367,6 +367,8 @@ PW_CASES = [
     (1, 7, 9, [(64, 0, 64, 0), (64, 0, 64, 0)], 128, "relu", False),            # one partial tile (63 pixels), runtime activation
     (2, 16, 16, [(192, 0, 320, 64)], 128, "silu", True),                        # a slice of a wider buffer, three chunks
     (5, 8, 8, [(64, 2, 64, 0), (128, 1, 192, 64)], 192, "silu", False),         # both segments upsampled (x4, x2)
+    (72, 40, 40, [(256, 0, 256, 0)], 256, "silu", False),                       # 900 workgroups: several tiles per workgroup
+    (64, 20, 20, [(256, 0, 256, 0), (256, 0, 256, 0)], 256, "silu", True),      # 200 workgroups, two segments, a residual
 ]
 
 
