@@ -632,13 +632,21 @@ class Compiler:
         l1 = self.csp("dark2.1", [self.down("dark2.0", l0)], bd, True, amff)
         l2 = self.csp("dark3.1", [self.down("dark3.0", l1)], n3, True, amff)
         l3 = self.csp("dark4.1", [self.down("dark4.0", l2)], bd * 3, True, amff)
-        side_gates = bool(c["vit"]) and not amff
+        # The gates of dark3 / dark4 (and dark2 in the four-level net) do not depend on dark5: on lane 3 they run beside it -- beside
+        # the fused Transformer in `net` (400 positions on 256 CUs leave CUs idle in its second round), beside the under-filled 20 x 20
+        # launches of dark5 in the other nets (three CBAMs one after the other were 7 % of net_deploy's step at 32 images).
+        # CCNET_SIDE_GATES=0 brings the sequential order back.
+        side_gates = os.environ.get("CCNET_SIDE_GATES", "1") != "0"
+        g1 = None
         if side_gates:
-            # the CBAM gates of dark3 / dark4 do not depend on dark5: on lane 3 they can fill the CUs that the fused
-            # Transformer (400 positions on 256 CUs) leaves idle in its second round
             ops.plan_wait(3, 0)
             ops.plan_set_lane(3)
-            g2, g3 = self.cbam("layer2_cbam", l2), self.cbam("layer3_cbam", l3)
+            if amff:
+                g2, g3 = self.eca("eca_3", l2), self.eca("eca_2", l3)
+            else:
+                g2, g3 = self.cbam("layer2_cbam", l2), self.cbam("layer3_cbam", l3)
+                if c["small"]:
+                    g1 = self.cbam("layer1_cbam", l1)
             ops.plan_set_lane(0)
         t = self.sppf("dark5.1", self.down("dark5.0", l3))
         tp["dark2"], tp["dark3"], tp["dark4"], tp["sppf"] = l1, l2, l3, t
@@ -649,11 +657,11 @@ class Compiler:
         else:
             l4 = self.csp("dark5.2", [t], bd, False, amff)
 
-        if amff:
-            g2, g3, g4 = self.eca("eca_3", l2), self.eca("eca_2", l3), self.eca("eca_1", l4)
-        elif side_gates:
-            g4 = self.cbam("layer4_cbam", l4)
+        if side_gates:
+            g4 = self.eca("eca_1", l4) if amff else self.cbam("layer4_cbam", l4)
             ops.plan_wait(0, 3)
+        elif amff:
+            g2, g3, g4 = self.eca("eca_3", l2), self.eca("eca_2", l3), self.eca("eca_1", l4)
         else:
             g2, g3, g4 = self.cbam("layer2_cbam", l2), self.cbam("layer3_cbam", l3), self.cbam("layer4_cbam", l4)
 
@@ -668,7 +676,8 @@ class Compiler:
             p2 = self.eca("eca_pa1", p2)
         p3 = None
         if c["small"]:
-            g1 = self.cbam("layer1_cbam", l1)
+            if g1 is None:
+                g1 = self.cbam("layer1_cbam", l1)
             fpn2 = self.base_conv("reduce_conv2", [p2])
             p3 = self.csp("C3_p2", [fpn2.up(), g1], nn_, False)
             p2 = self.csp("C3_n2", [self.base_conv("bu_conv3", [p3], 2), fpn2], nn_, False)
