@@ -85,6 +85,36 @@ def _scores_of(prediction, pred, num_classes):
 _nmax_guess = {}
 
 
+# Buffers of finished calls, reused by later calls of the same (B, A, rows, device): candidates, result rows + counts, NMS
+# workspace, keep indices and the pinned host copy.  Five allocations per call were a third of post_process' host time
+# (scripts/post_host_profile.py); a buffer set goes back only after its call's event has been waited for, so nothing on the GPU
+# still uses it, whichever stream the next call runs on.
+_pool = {}
+
+
+def _acquire(B, A, nmax, dev):
+    key = (B, A, nmax, str(dev))
+    with _cache_lock:
+        free = _pool.get(key)
+        if free:
+            return key, free.pop()
+    cand = torch.empty(B, A, 7, dtype=torch.float32, device=dev)
+    both = _result_buffer(B, nmax, dev)
+    ws = torch.empty(ops.nms_workspace_bytes(B, nmax) + 256, dtype=torch.uint8, device=dev)
+    keep_idx = torch.empty(B, nmax, dtype=torch.int32, device=dev)
+    host = torch.empty(both.numel(), dtype=torch.float32, pin_memory=True)
+    return key, (cand, both, ws, keep_idx, host)
+
+
+def _release(key, bufs):
+    with _cache_lock:
+        if key not in _pool and len(_pool) >= 16:
+            _pool.clear()
+        free = _pool.setdefault(key, [])
+        if len(free) < 4:
+            free.append(bufs)
+
+
 class PendingDetections:
     """Detections of one batch whose kernels and device->host copy have been submitted (post_process_async).  `result()` waits
     for the copy and returns what post_process returns.  Holding the object keeps every buffer the kernels use alive."""
@@ -96,28 +126,38 @@ class PendingDetections:
         dev = pred.device
         self.B, self.A, self.key = B, A, (B, A, str(dev))
         self.pred, self.nms_thres, self.image_hw = pred, nms_thres, image_hw
-        self.cand = torch.empty(B, A, 7, dtype=torch.float32, device=dev)
         with _cache_lock:
             nmax = _nmax_guess.get(self.key)
         if nmax is None:
             # first call for this (B, A, device): wait for the counts, then run NMS with the exact maximum
-            self.counts = torch.empty(B, dtype=torch.int32, device=dev)
-            ops.filter_candidates(pred, num_classes, conf_thres, self.cand, self.counts, scores)
-            self.nmax = min(max(int(self.counts.cpu().max()), 1), A)
-            self.both = _result_buffer(B, self.nmax, dev)
-            self.both[B * self.nmax * 7 + B:].view(torch.int32).copy_(self.counts)
+            cand = torch.empty(B, A, 7, dtype=torch.float32, device=dev)
+            counts = torch.empty(B, dtype=torch.int32, device=dev)
+            ops.filter_candidates(pred, num_classes, conf_thres, cand, counts, scores)
+            self._exact(cand, counts, min(max(int(counts.cpu().max()), 1), A))
         else:
             self.nmax = min(nmax, A)
-            self.both = _result_buffer(B, self.nmax, dev)
+            self.pool_key, self.bufs = _acquire(B, A, self.nmax, dev)
+            self.cand, self.both = self.bufs[0], self.bufs[1]
             # the filter kernel writes its counts straight into the result buffer
             self.counts = self.both[B * self.nmax * 7 + B:].view(torch.int32)
             ops.filter_candidates(pred, num_classes, conf_thres, self.cand, self.counts, scores)
+            self._submit()
+
+    def _exact(self, cand, counts, nmax):
+        """NMS over candidates that are already there, with rows for the known maximum."""
+        B, dev = self.B, cand.device
+        self.nmax = nmax
+        self.pool_key, self.bufs = _acquire(B, self.A, nmax, dev)
+        self.both = self.bufs[1]
+        self.both[B * nmax * 7 + B:].view(torch.int32).copy_(counts)
+        self.cand, self.counts = cand, counts
         self._submit()
 
     def _submit(self):
-        _nms(self.cand, self.counts, self.nmax, self.nms_thres, self.image_hw, self.both)
-        self.host = torch.empty(self.both.numel(), dtype=torch.float32, pin_memory=True)
-        self.host.copy_(self.both, non_blocking=True)
+        _, both, ws, keep_idx, host = self.bufs
+        _nms(self.cand, self.counts, self.nmax, self.nms_thres, self.image_hw, both, ws, keep_idx)
+        self.host = host
+        self.host.copy_(both, non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
 
@@ -135,19 +175,17 @@ class PendingDetections:
                     _nmax_guess.clear()
                 _nmax_guess[self.key] = min(A, max(64, -(-(cmax + cmax // 4) // 64) * 64))
             if cmax <= nmax:
-                det = host[:B * nmax * 7].reshape(B, nmax, 7)
-                nk = host[B * nmax * 7:B * nmax * 7 + B].view(np.int32)
-                self._done = [det[b, :nk[b]].copy() for b in range(B)]
-                self.pred = self.cand = self.both = self.counts = self.host = self.scores = None
+                # ONE copy out of the pinned buffer (it goes back to the pool), the per-image arrays are views of that copy
+                det = host[:B * nmax * 7].reshape(B, nmax, 7).copy()
+                nk = host[B * nmax * 7:B * nmax * 7 + B].view(np.int32).tolist()
+                self._done = [det[b, :nk[b]] for b in range(B)]
+                _release(self.pool_key, self.bufs)   # idle since the event; (after an exact re-launch the first attempt's set is dropped)
+                self.pred = self.cand = self.both = self.counts = self.host = self.scores = self.bufs = None
                 return self._done
             # an image had more candidates than the rows NMS was given (the kernels cut, never overrun): once more, exact
             with torch.cuda.device(self.cand.device):
-                counts = self.counts.clone()
-                self.nmax = min(cmax, A)
-                self.both = _result_buffer(B, self.nmax, self.cand.device)
-                self.both[B * self.nmax * 7 + B:].view(torch.int32).copy_(counts)
-                self.counts = counts
-                self._submit()
+                cand, counts = self.cand, self.counts.clone()
+                self._exact(cand, counts, min(cmax, A))
 
 
 def _result_buffer(B, nmax, dev):
@@ -155,17 +193,19 @@ def _result_buffer(B, nmax, dev):
     return torch.empty(B * nmax * 7 + 2 * B, dtype=torch.float32, device=dev)
 
 
-def _nms(cand, counts, nmax, nms_thres, image_hw, both=None):
+def _nms(cand, counts, nmax, nms_thres, image_hw, both=None, ws=None, keep_idx=None):
     B = cand.shape[0]
     dev = cand.device
-    ws = torch.empty(ops.nms_workspace_bytes(B, nmax) + 256, dtype=torch.uint8, device=dev)
+    if ws is None:
+        ws = torch.empty(ops.nms_workspace_bytes(B, nmax) + 256, dtype=torch.uint8, device=dev)
     off = (-ws.data_ptr()) % 256
     ws = ws[off:]
     if both is None:
         both = _result_buffer(B, nmax, dev)
     det = both[:B * nmax * 7].view(B, nmax, 7)
     nkeep = both[B * nmax * 7:B * nmax * 7 + B].view(torch.int32)
-    keep_idx = torch.empty(B, nmax, dtype=torch.int32, device=dev)
+    if keep_idx is None:
+        keep_idx = torch.empty(B, nmax, dtype=torch.int32, device=dev)
     ops.nms(cand, counts, nmax, nms_thres, image_hw, det, keep_idx, nkeep, ws)
     return det, keep_idx, nkeep, both
 
