@@ -171,7 +171,7 @@ def sharded_post_process(prediction, num_classes, input_shape, image_info, conf_
     out = []
     for r in range(world):
         rows = host[r, :n_rows].reshape(bmax, nmax, 7)
-        nk = host[r, n_rows:n_rows + bmax].view(np.int32)
+        nk = host[r, n_rows:n_rows + bmax].view(np.int32).tolist()
         for i in range(locals_[r]):
-            out.append(rows[i, :nk[i]].copy() if A else None)
+            out.append(rows[i, :nk[i]] if A else None)   # views: `host` is this call's own array
     return out
