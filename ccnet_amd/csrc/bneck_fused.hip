@@ -1,18 +1,22 @@
 // One Bottleneck of a CSPLayer in ONE launch (bf16): y = [x +] SiLU(conv3x3(SiLU(conv1x1(x)))), both convs BaseConv with BN folded,
-// C -> C -> C channels (network/model_block.py:193-218 with expansion 1.0, as CSPLayer builds it, :86-116), C = 64 or 128.
+// C -> C -> C channels (network/model_block.py:193-218 with expansion 1.0, as CSPLayer builds it, :86-116), C = 64, 128 or 256.
 //
-// Why: at 40 x 40 and 80 x 80 the pair is a 15 us 1x1 launch (3 GFLOP, latency-bound) whose output the 3x3 launch reads straight
+// Why: at 20 x 20 ... 80 x 80 the pair is a 15 us 1x1 launch (3 GFLOP, latency-bound) whose output the 3x3 launch reads straight
 // back.  Here the hidden map h never leaves the CU.  Per tile of 256 output pixels (conv_halo.hip's two geometries, 16 x 16 or 256
-// linear padded positions for narrow maps):
-//   1. x of the tile and its halo (352 rows x C) comes in by LDS-DMA as C/32 planes of 32 channels (64-byte rows, conv_halo's
-//      row swizzle), all at once -- the planes hold the whole K of the 1x1;
-//   2. phase 1: h = SiLU(W1 x + b1) for all 352 rows: wave w owns the 16-row m-tiles w, w + 4, ..; accumulators in registers;
+// linear padded positions for narrow maps; C = 256: 128 linear positions, maps up to 21 wide):
+//   1. x of the tile and its halo (352 rows x C; 176 at C = 256) comes in by LDS-DMA as C/32 planes of 32 channels (64-byte rows,
+//      conv_halo's row swizzle), all at once -- the planes hold the whole K of the 1x1;
+//   2. phase 1: h = SiLU(W1 x + b1) for all rows: wave w owns the 16-row m-tiles w, w + 4, ..; accumulators in registers;
 //   3. the waves overwrite the planes with h (bf16, ZERO where the row is outside the image: the 3x3 pads h, not x);
-//   4. phase 2: the nine taps over the C/32 resident planes, conv_halo's wave tiles (128 x 64 or 64 x 64), no barrier inside;
-//   5. the next tile's x is requested, then the epilogue (bias, SiLU, + x, store) runs while it arrives.
+//   4. phase 2: the nine taps over the C/32 resident planes, wave tiles of 64 x 64 (C = 64) or 128 pixels x 64 channels, no
+//      barrier inside; the next tap's pixel fragments are requested before the current tap's MFMAs;
+//   5. the tile's shortcut rows and the next tile's x are requested, then the epilogue (bias, SiLU, + x, store) runs while they arrive.
 // Weights never touch LDS: one stream per 64 output channels of the 3x3 in consumption order -- the 1x1's fragments (all of
-// them: every wave needs every output channel for its rows), then (plane, tap, n-tile) of the 3x3 -- behind an 8-fragment register
-// ring that runs ahead across phases and tiles (the stream ends with a copy of its head).
+// them: every wave needs every hidden channel for its rows), then (plane, tap, n-tile) of the 3x3 -- behind a register ring of 8
+// (C = 64) or 16 fragments that runs ahead across phases and tiles (the stream ends with a copy of its head).
+// LDS: C = 64 51 KB, two workgroups per CU; C >= 128 96 KB, one workgroup of four waves per CU (up to 512 registers per lane) --
+// there every SiLU is exposed (47 % of a tile's time, -DBK_STAMP), which is why graph.py takes those shapes only while every tile
+// finds a CU of its own.
 // Same MFMA shape, k order, bias placement and rounding points as the two separate launches: results are bit-identical to
 // ccnet_conv2d / ccnet_conv_pw followed by ccnet_conv_halo (tests/test_ops_gpu.py:test_bneck_fused_...).
 // The output must not alias the input: a tile's halo is its neighbours' output pixels.
