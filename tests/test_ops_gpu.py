@@ -479,6 +479,40 @@ def test_conv1x1_two_segments_equal_the_concatenated_buffer_bitwise(cout, cin):
     assert torch.equal(one.buf.view(torch.int16), two.buf.view(torch.int16))
 
 
+def test_bneck_fused_random_shapes_equal_the_two_launches_bitwise():
+    """40 seeded random problems (all three channel counts, both geometries, maps from 3 x 3 up, batches that give one tile and
+    several tiles per workgroup, with and without the shortcut, slices of wider buffers) against ccnet_conv2d + ccnet_conv_halo."""
+    ops = _ops()
+    rng = np.random.RandomState(11)
+    g = torch.Generator().manual_seed(11)
+    for case in range(40):
+        Cc = int(rng.choice([64, 128, 256]))
+        if Cc == 256:
+            H, W = int(rng.randint(3, 30)), int(rng.randint(3, 22))
+        else:
+            H, W = int(rng.randint(3, 70)), int(rng.randint(3, 90))
+        B = int(rng.choice([1, 2, 3, 7, 33])) if H * W < 1500 else int(rng.choice([1, 2, 5]))
+        if case % 10 == 0:
+            B = max(B, (600 * (128 if Cc == 256 else 256)) // (H * W) + 1)      # more tiles than workgroup slots
+        shortcut = bool(rng.randint(2))
+        ipad, opad = int(rng.choice([0, 8, 64])), int(rng.choice([0, 4, 32]))
+        x = torch.randn(B, Cc, H, W, generator=g)
+        w1 = torch.randn(Cc, Cc, 1, 1, generator=g) / math.sqrt(Cc)
+        b1 = torch.randn(Cc, generator=g) * 0.3
+        w2 = torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(9 * Cc)
+        b2 = torch.randn(Cc, generator=g) * 0.1
+        xt = to_nhwc(x, 1, ldc=Cc + ipad, coff=ipad)
+        xs = ops.sl(xt, ipad, Cc)
+        out = torch.zeros(B, H, W, Cc + opad, dtype=torch.bfloat16, device=DEV)
+        ref = torch.zeros_like(out)
+        hid = torch.zeros(B, H, W, Cc, dtype=torch.bfloat16, device=DEV)
+        ops.bneck_fused(xs, ops.PackedBneck(w1, b1, w2, b2, DEV), B, H, W, shortcut, "silu", ops.sl(out, opad, Cc))
+        ops.conv2d([xs], ops.PackedConv(w1, b1, 1, DEV), B, H, W, 1, 0, ops.sl(hid), "silu")
+        ops.conv_halo([ops.sl(hid)], ops.PackedHalo(w2, b2, DEV), 0, B, H, W, ops.sl(ref, opad, Cc), "silu", xs if shortcut else None)
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), (case, B, Cc, H, W, shortcut, ipad, opad)
+
+
 def test_bneck_fused_rejects_what_it_does_not_take():
     ops = _ops()
     pk = ops.PackedBneck(torch.zeros(64, 64, 1, 1), torch.zeros(64), torch.zeros(64, 64, 3, 3), torch.zeros(64), DEV)
