@@ -12,6 +12,7 @@
 // pooling block's CU slot about twice as long: pool 22 -> 42 us at 80x80x128 x 64 images, against the 11 us launch it saves.
 // Measured slower in total (0.217 against 0.192 ms for the three CBAMs of `net`), so the gate stays a launch of its own.
 #include <math.h>
+#include <mutex>
 #include "common.h"
 
 namespace {
@@ -152,14 +153,14 @@ __device__ inline void eca_gate_body(const float* pb, int nchunk, int C, int HW,
     }
 }
 
+// Sum and max per channel over the pixels of one (image, chunk): the work of one group of 256 threads (t = index in the group).
+// `red`: the group's [2][256][8] floats.  Contains block-wide barriers: every thread of the block calls it the same number of times;
+// a group without a chunk passes active = false.  dst: [2][C] partials of this chunk.
 template <typename T>
-__global__ __launch_bounds__(256) void pool_partial_kernel(const unsigned char* in, int ldc, int coff, int C, int HW, int nchunk, float* partial) {
-    __shared__ float red[2][256][8];
+__device__ inline void pool_partial_body(const unsigned char* img, int ldc, int C, int HW, int chunk, bool active, float* red, float* dst, int t) {
     const int G = C / 8;
-    const int b = blockIdx.y, chunk = blockIdx.x;
     const int p0 = chunk * POOL_CHUNK;
     const int p1 = min(HW, p0 + POOL_CHUNK);
-    const int t = threadIdx.x;
     for (int g0 = 0; g0 < G; g0 += 256) {
         const int TG = min(G - g0, 256);
         const int PL = 256 / TG;
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const unsigned char* 
         float s[8], m[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] = 0.0f; m[e] = -INFINITY; }
-        if (pl < PL) {
-            const unsigned char* src = in + (((size_t)b * HW) * ldc + coff + g * 8) * sizeof(T);
+        if (active && pl < PL) {
+            const unsigned char* src = img + (size_t)(g * 8) * sizeof(T);
             // 4 pixels in flight per thread (clamped index: no load behind a branch; a surplus pixel is loaded and not used)
             for (int pb = p0 + pl; pb < p1; pb += 4 * PL) {
                 float v[4][8];
@@ -183,24 +184,33 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const unsigned char* 
             }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { red[0][t][e] = s[e]; red[1][t][e] = m[e]; }
+        for (int e = 0; e < 8; ++e) { red[t * 8 + e] = s[e]; red[(256 + t) * 8 + e] = m[e]; }
         __syncthreads();
         // every thread finishes output values (sum | max, channel): PL reads each, in pixel-lane order
         const int nout = TG * 8;
-        float* dst = partial + (((size_t)b * nchunk + chunk) * 2) * C + g0 * 8;
-        for (int o = t; o < 2 * nout; o += 256) {
-            const int kind = o >= nout ? 1 : 0, rem = o - kind * nout;
-            const float* r = &red[kind][0][0] + rem;
-            float acc = r[0];
-            if (kind) {
-                for (int q = 1; q < PL; ++q) acc = fmaxf(acc, r[q * nout]);
-            } else {
-                for (int q = 1; q < PL; ++q) acc += r[q * nout];
+        if (active) {
+            for (int o = t; o < 2 * nout; o += 256) {
+                const int kind = o >= nout ? 1 : 0, rem = o - kind * nout;
+                const float* r = red + kind * 256 * 8 + rem;
+                float acc = r[0];
+                if (kind) {
+                    for (int q = 1; q < PL; ++q) acc = fmaxf(acc, r[q * nout]);
+                } else {
+                    for (int q = 1; q < PL; ++q) acc += r[q * nout];
+                }
+                dst[kind * C + g0 * 8 + rem] = acc;
             }
-            dst[kind * C + rem] = acc;
         }
         __syncthreads();
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_partial_kernel(const unsigned char* in, int ldc, int coff, int C, int HW, int nchunk, float* partial) {
+    __shared__ float red[2 * 256 * 8];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    pool_partial_body<T>(in + (((size_t)b * HW) * ldc + coff) * sizeof(T), ldc, C, HW, chunk, true, red, partial + (((size_t)b * nchunk + chunk) * 2) * C,
+                         threadIdx.x);
 }
 
 // one block per image; dynamic LDS: avg[C] max[C] hid[2*Cr] | 4 * blockDim floats for the split chunk reduction
@@ -227,14 +237,12 @@ __global__ __launch_bounds__(256) void eca_gate_kernel(const float* partial, int
 // at once (pixel slot + u * slots), so that it has GP_PIX 16-byte loads in flight and reads its channels' gate once.
 // One load per thread left the reads at 3.9 TB/s; the 64-bit index divisions of the first version cost as much as the loads.
 constexpr int GP_PIX = 4;
+// (mean, max) over the channels of x * ca for the GP_PIX pixels pbase + u * slots of one image; sub = the thread's lane among the LP
+// of its pixels.  src: the image's first element, ca_b / stats_b: the image's gate and its [HW][2] output.
 template <typename T>
-__global__ __launch_bounds__(256) void cbam_stats_kernel(const unsigned char* in, int ldc, int coff, int C, int HW, int lps, const float* ca,
-                                                         float* stats) {
-    const int G = C / 8, LP = 1 << lps, slots = 256 >> lps;
-    const int t = threadIdx.x, b = blockIdx.y;
-    const int sub = t & (LP - 1), slot = t >> lps;
-    const int pbase = blockIdx.x * (slots * GP_PIX) + slot;
-    const unsigned char* src = in + (((size_t)b * HW) * ldc + coff) * sizeof(T);
+__device__ inline void cbam_stats_body(const unsigned char* src, int ldc, int C, int HW, int lps, int slots, int pbase, int sub, const float* ca_b,
+                                       float* stats_b) {
+    const int G = C / 8, LP = 1 << lps;
     float s[GP_PIX], m[GP_PIX];
 #pragma unroll
     for (int u = 0; u < GP_PIX; ++u) { s[u] = 0.0f; m[u] = -INFINITY; }
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256) void cbam_stats_kernel(const unsigned char* in
         float v[GP_PIX][8];
 #pragma unroll
         for (int u = 0; u < GP_PIX; ++u) Chan8<T>::load(src + ((size_t)min(pbase + u * slots, HW - 1) * ldc + g * 8) * sizeof(T), v[u]);
-        const float4 c0 = *(const float4*)(ca + (size_t)b * C + g * 8), c1 = *(const float4*)(ca + (size_t)b * C + g * 8 + 4);
+        const float4 c0 = *(const float4*)(ca_b + g * 8), c1 = *(const float4*)(ca_b + g * 8 + 4);
         const float cg[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
         for (int u = 0; u < GP_PIX; ++u)
@@ -264,19 +272,25 @@ __global__ __launch_bounds__(256) void cbam_stats_kernel(const unsigned char* in
 #pragma unroll
         for (int u = 0; u < GP_PIX; ++u) {
             const int pix = pbase + u * slots;
-            if (pix < HW) *(float2*)(stats + ((size_t)b * HW + pix) * 2) = make_float2(s[u] / (float)C, m[u]);
+            if (pix < HW) *(float2*)(stats_b + (size_t)pix * 2) = make_float2(s[u] / (float)C, m[u]);
         }
     }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void cbam_apply_kernel(const unsigned char* in, int ldc, int coff, int C, int H, int W, int lps, const float* ca,
-                                                         const float* stats, const float* wk, int k, unsigned char* out, int out_ldc,
-                                                         int out_coff) {
-    const int G = C / 8, LP = 1 << lps, slots = 256 >> lps, HW = H * W;
+__global__ __launch_bounds__(256) void cbam_stats_kernel(const unsigned char* in, int ldc, int coff, int C, int HW, int lps, const float* ca,
+                                                         float* stats) {
+    const int LP = 1 << lps, slots = 256 >> lps;
     const int t = threadIdx.x, b = blockIdx.y;
-    const int sub = t & (LP - 1), slot = t >> lps;
-    const int pbase = blockIdx.x * (slots * GP_PIX) + slot;
+    cbam_stats_body<T>(in + (((size_t)b * HW) * ldc + coff) * sizeof(T), ldc, C, HW, lps, slots, blockIdx.x * (slots * GP_PIX) + (t >> lps), t & (LP - 1),
+                       ca + (size_t)b * C, stats + (size_t)b * HW * 2);
+}
+
+// sa = sigmoid(conv k x k over the (mean, max) planes), out = x * ca * sa for the same GP_PIX pixels
+template <typename T>
+__device__ inline void cbam_apply_body(const unsigned char* src, unsigned char* dst, int ldc, int out_ldc, int C, int H, int W, int lps, int slots,
+                                       int pbase, int sub, const float* ca_b, const float2* sp, const float* wk, int k) {
+    const int G = C / 8, LP = 1 << lps, HW = H * W;
     int py[GP_PIX], px[GP_PIX];
     float a[GP_PIX];
 #pragma unroll
@@ -288,7 +302,6 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(const unsigned char* in
     }
     // spatial gate: the k x k taps of the (mean, max) planes are spread over the LP lanes of a pixel; a tap's weights and offsets
     // are found once for the thread's GP_PIX pixels; a tap outside the image reads pixel 0 with zero weights (no branch)
-    const float2* sp = (const float2*)stats + (size_t)b * HW;
     const int pad = k / 2, kk = k * k;
     for (int tap = sub; tap < kk; tap += LP) {
         const int ky = tap / k, kx = tap - ky * k;
@@ -309,13 +322,11 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(const unsigned char* in
     float sa[GP_PIX];
 #pragma unroll
     for (int u = 0; u < GP_PIX; ++u) sa[u] = sigmoidf_(a[u]);
-    const unsigned char* src = in + (((size_t)b * HW) * ldc + coff) * sizeof(T);
-    unsigned char* dst = out + (((size_t)b * HW) * out_ldc + out_coff) * sizeof(T);
     for (int g = sub; g < G; g += LP) {
         float v[GP_PIX][8];
 #pragma unroll
         for (int u = 0; u < GP_PIX; ++u) Chan8<T>::load(src + ((size_t)min(pbase + u * slots, HW - 1) * ldc + g * 8) * sizeof(T), v[u]);
-        const float4 c0 = *(const float4*)(ca + (size_t)b * C + g * 8), c1 = *(const float4*)(ca + (size_t)b * C + g * 8 + 4);
+        const float4 c0 = *(const float4*)(ca_b + g * 8), c1 = *(const float4*)(ca_b + g * 8 + 4);
         const float cg[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
         for (int u = 0; u < GP_PIX; ++u) {
@@ -327,6 +338,53 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(const unsigned char* in
             }
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_apply_kernel(const unsigned char* in, int ldc, int coff, int C, int H, int W, int lps, const float* ca,
+                                                         const float* stats, const float* wk, int k, unsigned char* out, int out_ldc,
+                                                         int out_coff) {
+    const int LP = 1 << lps, slots = 256 >> lps, HW = H * W;
+    const int t = threadIdx.x, b = blockIdx.y;
+    cbam_apply_body<T>(in + (((size_t)b * HW) * ldc + coff) * sizeof(T), out + (((size_t)b * HW) * out_ldc + out_coff) * sizeof(T), ldc, out_ldc, C, H, W,
+                       lps, slots, blockIdx.x * (slots * GP_PIX) + (t >> lps), t & (LP - 1), ca + (size_t)b * C, (const float2*)stats + (size_t)b * HW, wk, k);
+}
+
+// The whole CBAM of one image in ONE workgroup of 1024 threads, for small maps (the 20 x 20 gate sits on every net's critical path as
+// four dependent launches of a few microseconds of work each; measured SLOWER than those, see ccnet_cbam: opt-in): the four passes above, back to back, with the partials, the gate and
+// the (mean, max) planes in LDS and x re-read from L2.  The same device functions in the same roles -- a group of 256 threads per
+// pixel chunk in the pooling, all 1024 in the MLP as cbam_mlp_kernel runs it, LP lanes per pixel in the two pixel passes -- so the
+// result is bit-identical to the four launches.  Dynamic LDS (floats): partial[nchunk][2][C] | red[4][2][256][8] | sm | tmp[4096] |
+// ca[C] | stats[HW][2].
+template <typename T>
+__global__ __launch_bounds__(1024) void cbam_image_kernel(const unsigned char* in, int ldc, int coff, int C, int Cr, int H, int W, int nchunk, int lps,
+                                                          const float* fc1, const float* fc2, const float* wk, int k, unsigned char* out, int out_ldc,
+                                                          int out_coff) {
+    extern __shared__ __align__(16) float gsm[];
+    const int HW = H * W, t = threadIdx.x, b = blockIdx.x;
+    float* partial = gsm;
+    float* red = partial + (size_t)nchunk * 2 * C;
+    float* sm = red + 4 * 2 * 256 * 8;
+    float* tmp = sm + ((2 * C + 2 * Cr + 3) & ~3);
+    float* ca_s = tmp + 4 * 1024;
+    float* stats_s = ca_s + C;
+    const unsigned char* src = in + (((size_t)b * HW) * ldc + coff) * sizeof(T);
+    unsigned char* dst = out + (((size_t)b * HW) * out_ldc + out_coff) * sizeof(T);
+    float warm = 0.0f;   // the MLP's weights on their way while the image is pooled (cbam_mlp_kernel)
+    for (int i = t * 32; i < Cr * C; i += 1024 * 32) warm += fc1[i] + fc2[i];
+    const int grp = t >> 8, tl = t & 255;
+    for (int c0 = 0; c0 < nchunk; c0 += 4) {
+        const int chunk = c0 + grp;
+        pool_partial_body<T>(src, ldc, C, HW, min(chunk, nchunk - 1), chunk < nchunk, red + grp * (2 * 256 * 8), partial + (size_t)min(chunk, nchunk - 1) * 2 * C, tl);
+    }
+    cbam_mlp_body(partial, nchunk, C, Cr, HW, fc1, fc2, ca_s, sm, tmp, t, 1024);
+    asm volatile("" ::"v"(warm));
+    __syncthreads();
+    const int LP = 1 << lps, slots = 1024 >> lps, sub = t & (LP - 1), slot = t >> lps;
+    for (int p0 = 0; p0 < HW; p0 += slots * GP_PIX) cbam_stats_body<T>(src, ldc, C, HW, lps, slots, p0 + slot, sub, ca_s, stats_s);
+    __syncthreads();
+    for (int p0 = 0; p0 < HW; p0 += slots * GP_PIX)
+        cbam_apply_body<T>(src, dst, ldc, out_ldc, C, H, W, lps, slots, p0 + slot, sub, ca_s, (const float2*)stats_s, wk, k);
 }
 
 template <typename T>
@@ -414,6 +472,14 @@ extern "C" int ccnet_cbam(ccnet_slice in, int dtype, int B, int H, int W, const 
     while ((1 << lps) < LP) ++lps;
     const int ppb = (256 / LP) * GP_PIX;  // pixels per block
     const dim3 pgrid((unsigned)((HW + ppb - 1) / ppb), (unsigned)B);
+    // small maps: the four passes in one workgroup per image (cbam_image_kernel; bit-identical) -- OPT-IN, CCNET_CBAM_IMAGE=1: at
+    // 64 x 20 x 20 x 512 it takes 67 us where the four launches take 46-49 (one workgroup per image is 64 CUs walking three passes at
+    // one CU's bandwidth; the four launches each use the whole chip).  Kept as the measured answer to "fewer launches" and for
+    // callers with many small gates in flight.  Shapes: maps up to 24 x 24 whose MLP runs on 1024 threads as a launch of its own
+    // (the summation order depends on the thread count).
+    const char* img_e = getenv("CCNET_CBAM_IMAGE");   // read per call (a call records or launches once): tests switch it
+    const size_t img_lds = ((size_t)gs.nchunk * 2 * C + 4 * 2 * 256 * 8 + ((2 * C + 2 * Cr + 3) & ~3) + 4 * 1024 + C + 2 * (size_t)HW) * sizeof(float);
+    const bool per_image = img_e && img_e[0] == '1' && HW <= 576 && 2 * Cr >= 64 && img_lds <= 150 * 1024;
     return ccnet_submit(
         [=](hipStream_t st, const float*) -> int {
             float* partial = scratch_dev + gs.partial;
@@ -423,6 +489,29 @@ extern "C" int ccnet_cbam(ccnet_slice in, int dtype, int B, int H, int W, const 
             unsigned char* op = (unsigned char*)out.ptr;
             const int mlp_threads = 2 * Cr >= 64 ? 1024 : 256;  // 8 hidden units per wave pass
             const size_t mlp_lds = (size_t)(((2 * C + 2 * Cr + 3) & ~3) + 4 * mlp_threads) * sizeof(float);
+            if (per_image) {
+                static std::mutex mu;
+                static size_t allowed[2][16] = {{0}};   // largest dynamic LDS size set per (dtype, device)
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+                const int ti = dtype == CCNET_BF16 ? 0 : 1;
+                {
+                    std::lock_guard<std::mutex> lock(mu);
+                    if (allowed[ti][dev] < 150 * 1024) {   // once, to the largest size the dispatch rule lets through
+                        const void* fn = dtype == CCNET_BF16 ? (const void*)cbam_image_kernel<__bf16> : (const void*)cbam_image_kernel<float>;
+                        CC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                        allowed[ti][dev] = 150 * 1024;
+                    }
+                }
+                if (dtype == CCNET_BF16)
+                    hipLaunchKernelGGL(cbam_image_kernel<__bf16>, dim3(B), dim3(1024), img_lds, st, ip, in.ldc, in.coff, C, Cr, H, W, gs.nchunk, lps, fc1, fc2,
+                                       w7, k7, op, out.ldc, out.coff);
+                else
+                    hipLaunchKernelGGL(cbam_image_kernel<float>, dim3(B), dim3(1024), img_lds, st, ip, in.ldc, in.coff, C, Cr, H, W, gs.nchunk, lps, fc1, fc2,
+                                       w7, k7, op, out.ldc, out.coff);
+                CC_LAUNCH_CHECK();
+                return CCNET_OK;
+            }
             if (dtype == CCNET_BF16) {
                 hipLaunchKernelGGL(pool_partial_kernel<__bf16>, dim3(gs.nchunk, B), dim3(256), 0, st, ip, in.ldc, in.coff, C, HW, gs.nchunk, partial);
                 hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(mlp_threads), mlp_lds, st, partial, gs.nchunk, C, Cr, HW, fc1, fc2, ca);

@@ -682,6 +682,33 @@ def test_cbam(code, Cc, H, W):
     assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("code", [0, 1])
+@pytest.mark.parametrize("B,Cc,H,W,k", [(64, 512, 20, 20, 7), (5, 256, 24, 24, 7), (3, 1024, 10, 10, 7), (2, 512, 7, 9, 3), (33, 512, 13, 21, 7)])
+def test_cbam_one_workgroup_per_image_equals_the_four_launches_bitwise(code, B, Cc, H, W, k, monkeypatch):
+    """Small maps run the whole gate in one workgroup per image (cbam_image_kernel): the same device functions in the same roles as
+    the four launches, so the outputs must be equal bit for bit -- and match torch (attention_block.py:19-22,44-48,65-70)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(29 + Cc + H)
+    x = torch.randn(B, Cc, H, W, generator=g)
+    cr = Cc // 8
+    fc1 = torch.randn(cr, Cc, generator=g) * 2 / math.sqrt(Cc)
+    fc2 = torch.randn(Cc, cr, generator=g) * 2 / math.sqrt(cr)
+    wk = torch.randn(2, k, k, generator=g) * 0.3
+    scratch = torch.zeros(ops.gate_scratch_floats(B, H, W, Cc), dtype=torch.float32, device=DEV)
+    xin, d1, d2, dk = to_nhwc(x, code, ldc=Cc + 8, coff=8), fc1.to(DEV), fc2.to(DEV), wk.to(DEV)
+    outs = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("CCNET_CBAM_IMAGE", env)
+        out = torch.zeros(B, H, W, Cc + 16, dtype=tdt(code), device=DEV)
+        ops.cbam(ops.sl(xin, 8, Cc), code, B, H, W, d1, d2, dk, scratch, ops.sl(out, 16, Cc))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    ref = _cbam_ref(q(x, code), fc1, fc2, wk)
+    assert rel(from_nhwc(outs[0], 16, Cc), ref) < (2e-5 if code == 0 else 6e-3)
+    assert float(outs[0][..., :16].float().abs().max()) == 0.0   # neighbours untouched
+
+
 def test_gates_are_run_to_run_identical_and_batch_independent_on_a_large_map():
     """80x80x128, 64 images: 50 pooling blocks per image, the chunk partials summed in a fixed order split over thread groups;
     the output must not change between launches, and an image alone must equal the image in the batch."""
