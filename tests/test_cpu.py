@@ -196,6 +196,63 @@ def test_pack_layouts():
     assert float(pc.weight[5:].abs().max()) == 0 and float(pc.weight[:, 72:].abs().max()) == 0
 
 
+def test_fragment_stream_layouts_follow_the_header():
+    """include/ccnet_hip.h describes the weight streams of ccnet_conv_halo, ccnet_conv_pw and ccnet_bneck_fused fragment by fragment
+    (one MFMA A operand = [64 lanes][8]: lane l holds row l & 15, k (l >> 4) * 8 .. + 7).  Packed on the CPU with weights that encode
+    their own (output channel, input channel, tap), every fragment must sit where the header says."""
+    from ccnet_amd import ops
+
+    def coded(cout, cin, kh):
+        o = torch.arange(cout, dtype=torch.float64).view(cout, 1, 1, 1)
+        c = torch.arange(cin, dtype=torch.float64).view(1, cin, 1, 1)
+        t = torch.arange(kh * kh, dtype=torch.float64).view(1, 1, kh, kh)
+        return (o + 0 * c + 0 * t).expand(cout, cin, kh, kh), (c + 0 * o + 0 * t).expand(cout, cin, kh, kh), (t + 0 * o + 0 * c).expand(cout, cin, kh, kh)
+
+    def frag(stream, n64, f):
+        return stream[n64, f].reshape(4, 16, 8).float()      # [kq][row][e]
+
+    # ccnet_conv_halo: per 64 output channels: chunk of 32 input channels, tap, 16-row n-tile; then the first 9 fragments again
+    cout, cin = 128, 64
+    wo, wc, wt = coded(cout, cin, 3)
+    so, sc, st = (ops.PackedHalo(w, None, "cpu").weight for w in (wo, wc, wt))
+    assert so.shape == (2, (cin // 32) * 36 + 9, 512)
+    for n64, cc, tap, j in ((0, 0, 0, 0), (1, 1, 5, 3), (0, 1, 8, 2)):
+        f = cc * 36 + tap * 4 + j
+        assert torch.equal(frag(so, n64, f)[:, :, 0], (n64 * 64 + j * 16 + torch.arange(16.0)).expand(4, 16))
+        assert torch.equal(frag(sc, n64, f)[:, 0, :], cc * 32 + torch.arange(32.0).view(4, 8))
+        assert float(frag(st, n64, f).min()) == float(frag(st, n64, f).max()) == tap
+    assert torch.equal(so[:, -9:], so[:, :9]) and torch.equal(sc[:, -9:], sc[:, :9])
+    # ccnet_conv_pw: per 64 output channels: k-step of 32, n-tile; then the first 8 again
+    wo, wc, _ = coded(128, 128, 1)
+    so, sc = (ops.PackedPw(w, None, "cpu").weight for w in (wo, wc))
+    assert so.shape == (2, 4 * 4 + 8, 512)
+    f = 2 * 4 + 1
+    assert torch.equal(frag(so, 1, f)[:, :, 0], (64 + 16 + torch.arange(16.0)).expand(4, 16))
+    assert torch.equal(frag(sc, 1, f)[:, 0, :], 64 + torch.arange(32.0).view(4, 8))
+    assert torch.equal(so[:, -8:], so[:, :8])
+    # ccnet_bneck_fused: per 64 output channels of conv2: ALL of conv1 (k-step major, n-tile), conv2 in conv_halo's order, the head again
+    for c, ring in ((64, 8), (128, 16), (256, 16)):
+        o1, c1, _ = coded(c, c, 1)
+        o2, c2, t2 = coded(c, c, 3)
+        zero1, zero2 = torch.zeros(c, c, 1, 1, dtype=torch.float64), torch.zeros(c, c, 3, 3, dtype=torch.float64)
+        b = torch.zeros(c)
+        f1 = (c // 32) * (c // 16)
+        s_o1 = ops.PackedBneck(o1, b, zero2, b, "cpu").weight
+        s_c1 = ops.PackedBneck(c1, b, zero2, b, "cpu").weight
+        s_o2 = ops.PackedBneck(zero1, b, o2, b, "cpu").weight
+        s_t2 = ops.PackedBneck(zero1, b, t2, b, "cpu").weight
+        assert s_o1.shape == (c // 64, f1 + (c // 32) * 36 + ring, 512)
+        ks, nt = c // 32 - 1, c // 16 - 1
+        for n64 in range(c // 64):                                  # conv1 is the same in every block's stream
+            assert torch.equal(frag(s_o1, n64, ks * (c // 16) + nt)[:, :, 0], (nt * 16 + torch.arange(16.0)).expand(4, 16))
+            assert torch.equal(frag(s_c1, n64, ks * (c // 16) + nt)[:, 0, :], ks * 32 + torch.arange(32.0).view(4, 8))
+        n64, cc, tap, j = c // 64 - 1, c // 32 - 1, 7, 2
+        f = f1 + cc * 36 + tap * 4 + j
+        assert torch.equal(frag(s_o2, n64, f)[:, :, 0], (n64 * 64 + j * 16 + torch.arange(16.0)).expand(4, 16))
+        assert float(frag(s_t2, n64, f).min()) == float(frag(s_t2, n64, f).max()) == tap
+        assert torch.equal(s_o1[:, -ring:], s_o1[:, :ring])
+
+
 # ----------------------------------------------------------------------------- C ABI surface
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "ccnet_hip.h")).read()
@@ -217,6 +274,13 @@ def test_c_abi_validates_before_launching():
     assert L.ccnet_conv2d(ctypes.byref(d), None) == -1 and b"nseg" in L.ccnet_last_error()
     assert L.ccnet_layernorm(None, None, None, None, None, 1, 4, 256, 1e-5, None) == -1
     assert L.ccnet_nms_workspace_bytes(2, 100) > 2 * 128 * 2 * 8
+    x = _lib.Slice(0x1000, 64, 0, 64, 0)
+    assert L.ccnet_bneck_fused(x, 1, 8, 8, 0x2000, 0x3000, 0x4000, 1, _lib.ACT["silu"], x, None) == -1 and b"overlaps" in L.ccnet_last_error()
+    y = _lib.Slice(0x100000, 64, 0, 64, 0)
+    assert L.ccnet_bneck_fused(x, 1, 8, 8, 0x2000, 0x3000, 0x4000, 1, _lib.ACT["relu"], y, None) == -1 and b"SiLU" in L.ccnet_last_error()
+    x256 = _lib.Slice(0x1000, 256, 0, 256, 0)
+    assert L.ccnet_bneck_fused(x256, 1, 8, 30, 0x2000, 0x3000, 0x4000, 1, _lib.ACT["silu"], _lib.Slice(0x100000, 256, 0, 256, 0), None) == -1
+    assert L.ccnet_bneck_fused_stream_elems(96) == 0 and L.ccnet_bneck_fused_stream_elems(64) == (8 + 72 + 8) * 512
     h = ctypes.c_void_p()
     assert L.ccnet_plan_begin(ctypes.byref(h)) == 0
     assert L.ccnet_plan_begin(ctypes.byref(ctypes.c_void_p())) == -1          # one open plan per thread
